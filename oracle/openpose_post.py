@@ -1,0 +1,270 @@
+"""ORACLE (test infrastructure only): numpy restatement of OpenPose
+post-processing.  Never imported by the product path (`terran_amd/`).
+
+Follows terran/pose/openpose/wrapper.py:
+  bicubic_x8        : 214-223  (torch F.interpolate bicubic, align_corners=False, A=-0.75; torch is
+                      importable in the build container, so this restatement is pinned bit-exactly
+                      against torch CPU by tests/golden/make_golden.py)
+  find_peaks        : 235-262
+  score_limb        : 274-333  (+ build_segments 125-163: torch.linspace -> trunc)
+  greedy_match      : 335-366
+  assemble_humans   : 368-478
+  keypoints_out     : 37-90
+  postprocess       : 225-485 (whole per-image tail)
+
+Tie rule for the candidate sort (reference: np.argsort(-score), unspecified for
+ties): stable, i.e. row-major (src, dst) order first.
+All "float32" steps below round after every single operation (no FMA), which is
+what torch's CPU element-wise kernels do.
+"""
+import numpy as np
+
+from terran_amd.arch import MAP_IDX, LIMBSEQ
+
+F32 = np.float32
+NUM_MIDPOINTS = 10
+KEYPOINT_THRESHOLD = 0.1      # wrapper.py:178
+MIDPOINT_THRESHOLD = 0.05     # wrapper.py:179 (thresh_2)
+HUMAN_THRESHOLD = 0.4         # wrapper.py:180
+
+
+# ----------------------------------------------------------------------------
+# bicubic x8
+# ----------------------------------------------------------------------------
+def cubic_coeffs(t):
+    """4 float32 taps for fractional offset t (float32), A=-0.75 (ATen
+    get_cubic_upsample_coefficients)."""
+    A = F32(-0.75)
+    t = F32(t)
+
+    def c1(x):   # |x| <= 1
+        return F32(F32(F32(F32(F32(A + F32(2)) * x) - F32(A + F32(3))) * x) * x) + F32(1)
+
+    def c2(x):   # 1 < |x| < 2
+        return F32(F32(F32(F32(F32(F32(A * x) - F32(F32(5) * A)) * x) + F32(F32(8) * A)) * x) - F32(F32(4) * A))
+
+    x2 = F32(F32(1) - t)
+    return np.array([c2(F32(t + F32(1))), c1(t), c1(x2), c2(F32(x2 + F32(1)))], F32)
+
+
+def _axis_plan(in_size, scale=8):
+    """Per output index: 4 clamped source indices and 4 float32 weights."""
+    out_size = in_size * scale
+    idx = np.empty((out_size, 4), np.int64)
+    wts = np.empty((out_size, 4), F32)
+    inv = F32(1.0 / scale)
+    for d in range(out_size):
+        real = F32(F32(inv * F32(d + 0.5)) - F32(0.5))
+        fl = np.floor(real)
+        t = F32(real - fl)
+        i0 = int(fl)
+        for k in range(4):
+            idx[d, k] = min(max(i0 - 1 + k, 0), in_size - 1)
+        wts[d] = cubic_coeffs(t)
+    return idx, wts
+
+
+def _fma(a, b, c):
+    """float32 fused multiply-add emulated through float64 (the product of two
+    float32 is exact in float64; the single float64 rounding of the sum can differ
+    from a true fma only on ~2^-29 of inputs)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(F32)
+
+
+def _tap_chain(v, w):
+    """ATen's 4-tap accumulation as compiled in torch 2.10 CPU (pinned bit-exactly
+    by make_golden.py): fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1)))."""
+    r = (v[1] * w[1]).astype(F32)
+    for k in (0, 2, 3):
+        r = _fma(v[k], w[k], r)
+    return r
+
+
+def bicubic_x8(x):
+    """x (..., h, w) float32 -> (..., 8h, 8w) float32.  Horizontal 4-tap chain on
+    each of the four source rows, then the same chain vertically."""
+    x = np.asarray(x, dtype=F32)
+    h, w = x.shape[-2:]
+    iy, wy = _axis_plan(h)
+    ix, wx = _axis_plan(w)
+    g = x[..., :, ix]                                  # (..., h, 8w, 4)
+    rows = _tap_chain([g[..., k] for k in range(4)], [wx[:, k] for k in range(4)])
+    g = rows[..., iy, :]                               # (..., 8h, 4, 8w)
+    return _tap_chain([g[..., k, :] for k in range(4)], [wy[:, k][:, None] for k in range(4)])
+
+
+# ----------------------------------------------------------------------------
+# peaks
+# ----------------------------------------------------------------------------
+def find_peaks(heatmaps):
+    """heatmaps (19,H,W) float32 (upsampled) -> list of 18 (locs (n,2) int64 (y,x),
+    scores (n,) float32).  Interior pixels only; >= against the 4 neighbours and
+    >= 0.1; row-major order."""
+    out = []
+    thr = F32(KEYPOINT_THRESHOLD)
+    for part in range(18):
+        m = heatmaps[part]
+        c = m[1:-1, 1:-1]
+        binary = ((c >= m[0:-2, 1:-1]) & (c >= m[1:-1, :-2]) & (c >= m[2:, 1:-1])
+                  & (c >= m[1:-1, 2:]) & (c >= thr))
+        locs = np.argwhere(binary) + 1
+        out.append((locs.astype(np.int64), m[locs[:, 0], locs[:, 1]].astype(F32)))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# PAF line-integral scoring
+# ----------------------------------------------------------------------------
+def _linspace_trunc(a, b):
+    """trunc(torch.linspace(a, b, 10)) for integer-valued a, b (broadcast arrays).
+    float32: step=(b-a)/9; v_i = a + step*i for i<5, b - step*(9-i) otherwise."""
+    a = a.astype(F32)
+    b = b.astype(F32)
+    step = (b - a) / F32(NUM_MIDPOINTS - 1)
+    pts = []
+    for i in range(NUM_MIDPOINTS):
+        if i < NUM_MIDPOINTS // 2:
+            v = a + step * F32(i)
+        else:
+            v = b - step * F32(NUM_MIDPOINTS - 1 - i)
+        pts.append(np.trunc(v).astype(np.int64))
+    return np.stack(pts, 0)                    # (10, Ns, Nd)
+
+
+def score_limb(pafs, limb_id, loc_src, loc_dst):
+    """pafs (38,H,W) float32 upsampled.  Returns (reg_scores (Ns,Nd) float32,
+    accept (Ns,Nd) bool)."""
+    cx, cy = MAP_IDX[limb_id][0] - 19, MAP_IDX[limb_id][1] - 19
+    H_up = pafs.shape[1]
+    d = (loc_dst[None, :, :] - loc_src[:, None, :]).astype(F32)        # (Ns,Nd,2) = (dy,dx)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        norms = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(F32)
+        dy = d[..., 0] / norms
+        dx = d[..., 1] / norms
+        ys = _linspace_trunc(loc_src[:, None, 0] + 0 * loc_dst[None, :, 0],
+                             loc_dst[None, :, 0] + 0 * loc_src[:, None, 0])
+        xs = _linspace_trunc(loc_src[:, None, 1] + 0 * loc_dst[None, :, 1],
+                             loc_dst[None, :, 1] + 0 * loc_src[:, None, 1])
+        px = pafs[cx][ys, xs]                                         # (10,Ns,Nd)
+        py = pafs[cy][ys, xs]
+        mid = (px * dx[None]) + (py * dy[None])                       # two rounded products, one add
+        total = mid[0]
+        for i in range(1, NUM_MIDPOINTS):
+            total = total + mid[i]
+        pen = np.minimum(F32(0.5 * H_up) / norms - F32(1), F32(0))
+        reg = total / F32(NUM_MIDPOINTS) + pen
+        crit1 = (mid > F32(MIDPOINT_THRESHOLD)).sum(0) > 0.8 * NUM_MIDPOINTS
+        crit2 = reg > F32(0)
+    return reg.astype(F32), (crit1 & crit2)
+
+
+def greedy_match(reg, accept):
+    """-> list of (i, j, score float32) following wrapper.py:335-359, including
+    the single `seen` set shared by source and destination indices."""
+    ns, nd = reg.shape
+    cand = np.argwhere(accept)                       # row-major
+    if cand.shape[0] == 0:
+        return []
+    sc = reg[cand[:, 0], cand[:, 1]]
+    order = np.argsort(-sc, kind='stable')
+    conns, seen = [], set()
+    for i, j in cand[order]:
+        i, j = int(i), int(j)
+        if i not in seen and j not in seen:
+            conns.append((i, j, reg[i, j]))
+            if len(conns) >= min(ns, nd):
+                break
+            seen.add(i)
+            seen.add(j)
+    return conns
+
+
+# ----------------------------------------------------------------------------
+# assembly
+# ----------------------------------------------------------------------------
+def assemble_humans(peaks, connections_per_limb):
+    """peaks: list[18] of (locs, scores); connections_per_limb: list[19] of None
+    (limb missing: an endpoint part has no peaks) or list of (i, j, score).
+    Returns (peaks_by_id (P,3) float64 [y,x,score], humans (M,20) float64)."""
+    offs = np.cumsum([0] + [p[0].shape[0] for p in peaks])
+    rows = [(float(y), float(x), float(s)) for locs, scs in peaks for (y, x), s in zip(locs, scs)]
+    peaks_by_id = np.array(rows, dtype=np.float64).reshape(-1, 3)
+
+    humans = []       # each: np.float64 (20,): 18 peak ids (-1 absent), [18]=score sum, [19]=count
+    for limb_id in range(19):
+        conns = connections_per_limb[limb_id]
+        if conns is None:
+            continue
+        ks, kd = LIMBSEQ[limb_id][0] - 1, LIMBSEQ[limb_id][1] - 1
+        for (i, j, s) in conns:
+            a = float(offs[ks] + i)
+            b = float(offs[kd] + j)
+            s = float(s)
+            hit = [h for h in range(len(humans)) if humans[h][ks] == a or humans[h][kd] == b]
+            if len(hit) == 1:
+                hm = humans[hit[0]]
+                if hm[kd] != b:
+                    hm[kd] = b
+                    hm[19] += 1
+                    hm[18] += peaks_by_id[int(b), 2] + s
+            elif len(hit) == 2:
+                h1, h2 = humans[hit[0]], humans[hit[1]]
+                overlap = np.any((h1[:18] >= 0) & (h2[:18] >= 0))
+                if not overlap:
+                    h1[:18] += h2[:18] + 1
+                    h1[18:] += h2[18:]
+                    h1[18] += s
+                    del humans[hit[1]]
+                else:
+                    h1[kd] = b
+                    h1[19] += 1
+                    h1[18] += peaks_by_id[int(b), 2] + s
+            elif len(hit) == 0 and limb_id < 17:
+                hm = -np.ones(20, np.float64)
+                hm[ks], hm[kd] = a, b
+                hm[19] = 2
+                hm[18] = (0 + peaks_by_id[int(a), 2] + peaks_by_id[int(b), 2]) + s
+                humans.append(hm)
+    kept = [h for h in humans if not (h[19] < 4 or h[18] / h[19] < HUMAN_THRESHOLD)]
+    humans = np.array(kept, dtype=np.float64).reshape(-1, 20)
+    return peaks_by_id, humans
+
+
+def keypoints_out(peaks_by_id, humans, scale):
+    out = []
+    for hm in humans:
+        kp = np.zeros((18, 3), np.int32)
+        for j in range(18):
+            pid = np.int32(hm[j])
+            if pid != -1:
+                y, x = peaks_by_id[pid][:2]
+                kp[j] = (np.int32(x / scale), np.int32(y / scale), 1)
+        out.append({'keypoints': kp, 'score': hm[18] / hm[19]})
+    return out
+
+
+def group_image(heatmaps_up, pafs_up, scale, debug=None):
+    """Per-image tail on UPSAMPLED maps: (19,H,W), (38,H,W) -> list of dicts."""
+    peaks = find_peaks(heatmaps_up)
+    conns = []
+    for limb_id in range(19):
+        ks, kd = LIMBSEQ[limb_id][0] - 1, LIMBSEQ[limb_id][1] - 1
+        ls, ld = peaks[ks][0], peaks[kd][0]
+        if ls.shape[0] == 0 or ld.shape[0] == 0:
+            conns.append(None)
+            continue
+        reg, acc = score_limb(pafs_up, limb_id, ls, ld)
+        conns.append(greedy_match(reg, acc))
+    peaks_by_id, humans = assemble_humans(peaks, conns)
+    if debug is not None:
+        debug['peaks'] = peaks
+        debug['connections'] = conns
+        debug['humans'] = humans
+    return keypoints_out(peaks_by_id, humans, scale)
+
+
+def postprocess(pafs, heatmaps, scale):
+    """Network outputs (N,38,h,w), (N,19,h,w) float32 -> list[N] of list[dict]."""
+    pafs_up = bicubic_x8(pafs)
+    hm_up = bicubic_x8(heatmaps)
+    return [group_image(hm_up[n], pafs_up[n], scale) for n in range(pafs.shape[0])]
