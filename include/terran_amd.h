@@ -1,0 +1,142 @@
+/* terran_amd.h -- C ABI of the MI355X-native (gfx950) per-frame human-perception path.
+ *
+ * This is the drop-in boundary for Terran's three model wrappers: the functions below
+ * are exactly what a binding for the reference's plugin classes
+ *
+ *     terran/face/detection/retinaface/wrapper.py:92-238   class RetinaFace  (.call)
+ *     terran/face/recognition/arcface/wrapper.py:102-184   class ArcFace     (.call)
+ *     terran/pose/openpose/wrapper.py:166-485              class OpenPose    (.call)
+ *
+ * (selected through the checkpoint registry, terran/checkpoint.py:29-103,213-245) calls
+ * instead of running torch.nn graphs + torch/numpy post-processing.  `terran_amd/` holds the
+ * ctypes binding and the Python mirror of those classes; INTEGRATION.md shows the registry
+ * entries a Terran maintainer would add.
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers and sizes only; no exceptions cross the ABI.
+ *   - every function returns TA_OK (0) or a negative TA_E_* code; ta_last_error(ctx) holds the text.
+ *   - all pointers are HOST memory unless the name ends in _dev.
+ *   - variable-length results use caller-allocated arrays with a `capacity` (in objects) and a
+ *     `required` out-value; TA_E_CAPACITY is returned (nothing truncated silently) when too small.
+ *   - one ta_ctx per GPU; a ctx and everything created from it belong to ONE host thread.
+ *   - there is NO CPU fallback: every entry point fails with TA_E_DEVICE when no gfx950 device
+ *     is usable.
+ */
+#ifndef TERRAN_AMD_H
+#define TERRAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_OK 0
+#define TA_E_INVALID (-1)   /* bad argument / malformed model blob            */
+#define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
+#define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
+#define TA_E_OVERFLOW (-4)  /* an internal per-image working limit was hit    */
+
+#define TA_MODEL_RETINAFACE 1
+#define TA_MODEL_ARCFACE 2
+#define TA_MODEL_OPENPOSE 3
+
+typedef struct ta_ctx ta_ctx;       /* one per device: stream, scratch, error text           */
+typedef struct ta_model ta_model;   /* packed weights + op program + per-shape activation plan */
+typedef struct ta_frames ta_frames; /* a batch of uint8 RGB frames resident in HBM (N,H,W,3)   */
+
+/* ---- context -------------------------------------------------------------------------- */
+const char* ta_version(void);
+int ta_device_count(void);
+int ta_ctx_create(int device_id, ta_ctx** out);
+void ta_ctx_destroy(ta_ctx* ctx);
+const char* ta_last_error(const ta_ctx* ctx);
+int ta_ctx_sync(ta_ctx* ctx);
+/* Per-kernel-class HIP-event timing (bench.py `roofline`): enable, run, then read.
+ * klass: 0 = implicit-GEMM conv, 1 = depthwise/pool/elementwise, 2 = pre-processing,
+ * 3 = post-processing.  ms = summed event time, launches = #kernels, work = algorithmic
+ * FLOP (klass 0) or bytes (others) summed over those launches. */
+int ta_profile_enable(ta_ctx* ctx, int on);
+int ta_profile_reset(ta_ctx* ctx);
+int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, double* work);
+/* Event pair on the ctx stream (whole-step timing). */
+int ta_timer_start(ta_ctx* ctx);
+int ta_timer_stop(ta_ctx* ctx, double* ms);
+
+/* ---- frames (replaces `torch.as_tensor(images, device=...)`,
+ *      retinaface/wrapper.py:144, openpose/wrapper.py:121, arcface/wrapper.py:170) -------- */
+int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, ta_frames** out);
+int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out);
+int ta_frames_shape(const ta_frames* f, int* n, int* h, int* w);
+int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb);
+void ta_frames_free(ta_frames* f);
+/* cv2.resize(..., INTER_LINEAR) semantics on the device
+ * (face/detection/__init__.py:33-38, pose/openpose/wrapper.py:106-111). */
+int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out);
+/* Zero-pad `src` image `src_index` into image `dst_index` of `dst` at (top, left)
+ * (merge_in, face/detection/__init__.py:96-139 / pose/__init__.py:48-88). */
+int ta_frames_paste(ta_ctx* ctx, const ta_frames* src, int src_index, ta_frames* dst, int dst_index,
+                    int top, int left);
+
+/* ---- models ---------------------------------------------------------------------------- */
+/* `blob` is the packed model produced by terran_amd/pack.py from a Terran state_dict
+ * (replaces load_model(): retinaface/wrapper.py:16-22, arcface/wrapper.py:13-19,
+ * openpose/wrapper.py:27-36).  The blob is copied; the caller may free it. */
+int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_model** out);
+void ta_model_free(ta_model* m);
+int ta_model_kind(const ta_model* m);
+
+/* Debug taps for parity tests: run only the network on `frames` (RetinaFace / OpenPose) or on
+ * uint8 BGR CHW crops (ArcFace), then read any tensor of the op program back as float32 NCHW.
+ * `tensor` is a tensor id of the packed program; `ch_off/ch` select a channel slice. */
+int ta_model_forward_frames(ta_model* m, const ta_frames* frames);
+int ta_model_forward_crops(ta_model* m, const uint8_t* crops_nchw_bgr, int n);
+int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* w);
+int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst_nchw);
+
+/* ---- RetinaFace.call (retinaface/wrapper.py:133-238) ------------------------------------ */
+/* frames: (N,H,W,3) uint8 RGB at network resolution.  Per image: threshold (>=), sort by
+ * descending score (ties: ascending anchor index), greedy NMS (IoU > nms_thr suppressed).
+ * Results are concatenated over images in order; counts[i] = detections of image i.
+ * boxes (x1,y1,x2,y2), landmarks 5x(x,y), network-input pixels, float32. */
+int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, float nms_thr,
+                      int capacity, int32_t* counts, float* boxes, float* landmarks, float* scores,
+                      int32_t* required);
+/* Post-processing only, on host head tensors in the reference layout (nine NCHW float32 arrays,
+ * order stride 32,16,8 x cls_prob(4ch), bbox(8ch), landmark(20ch); model.py:304-316). */
+int ta_retinaface_postprocess(ta_ctx* ctx, const float* const heads[9], int n, int h, int w,
+                              float score_thr, float nms_thr, int capacity, int32_t* counts,
+                              float* boxes, float* landmarks, float* scores, int32_t* required);
+
+/* ---- ArcFace.call (arcface/wrapper.py:109-184) ------------------------------------------ */
+/* Embed n pre-cropped faces, uint8 (n,3,112,112) BGR.  normalize != 0 applies the row-wise L2
+ * normalisation of wrapper.py:176.  out: (n,512) float32. */
+int ta_arcface_embed_crops(ta_model* m, const uint8_t* crops_nchw_bgr, int n, int normalize, float* out);
+/* Align + embed on the device: face k is warped from frames[frame_index[k]] with the inverse
+ * similarity inv_affine[k] (6 doubles, PIL Image.transform(AFFINE) convention, wrapper.py:61-69),
+ * bilinear, fill 0, to 112x112 BGR.  crops_out (optional, may be NULL): (n,3,112,112) uint8. */
+int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* frame_index,
+                           const double* inv_affine, int n, int normalize, float* out,
+                           uint8_t* crops_out);
+/* Cosine distance matrix 1 - a.b/(|a||b|) (examples/match.py:38): a (na,dim), b (nb,dim) -> (na,nb). */
+int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int nb, int dim, float* out);
+
+/* ---- OpenPose.call (openpose/wrapper.py:182-485) ---------------------------------------- */
+/* frames: uint8 RGB ALREADY at network resolution (the wrapper's resize is ta_frames_resize);
+ * scale = short_side / min(H_orig, W_orig) maps keypoints back ((coord/scale) truncated).
+ * keypoints: (M,18,3) int32 (x, y, present); scores: (M,) float64; counts[i] humans of image i. */
+int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capacity,
+                    int32_t* counts, int32_t* keypoints, double* scores, int32_t* required);
+/* Grouping only (x8 bicubic, peaks, PAF scoring, greedy matching, assembly) on host maps at
+ * network-output resolution: pafs (N,38,h,w), heatmaps (N,19,h,w) float32 NCHW. */
+int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w,
+                      double scale, int capacity, int32_t* counts, int32_t* keypoints,
+                      double* scores, int32_t* required);
+/* x8 bicubic upsample alone (wrapper.py:214-223): maps (N,C,h,w) -> (N,C,8h,8w). */
+int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERRAN_AMD_H */

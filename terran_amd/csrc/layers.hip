@@ -1,0 +1,174 @@
+// HBM-bound layer kernels (NHWC float32, 16-byte vector accesses, channel-fastest threads):
+// depthwise 3x3 (+folded BN bias, ReLU), 2x2 max-pool, channel-slice copy, and the uint8 ->
+// float pre-processing of the three wrappers.
+#include "ta_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- depthwise 3x3 (retinaface/model.py:32-39,65-67) ---------------------------------------
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const ta_dw_launch p) {
+  const int c4 = p.C >> 2;
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c4);
+    size_t pix = i / c4;
+    const int x = (int)(pix % p.Wo);
+    pix /= p.Wo;
+    const int y = (int)(pix % p.Ho);
+    const int img = (int)(pix / p.Ho);
+    const float* src = p.in + (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row +
+                       (size_t)(x * p.stride) * p.in_pix + p.in_off0 + cg * 4;
+    f32x4 acc = *(const f32x4*)(p.bias + cg * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f32x4 v = *(const f32x4*)(src + (size_t)ky * p.in_row + (size_t)kx * p.in_pix);
+        const f32x4 w = *(const f32x4*)(p.w + (ky * 3 + kx) * p.C + cg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v[e], w[e], acc[e]);
+      }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+    }
+    *(f32x4*)(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0 +
+              cg * 4) = acc;
+  }
+}
+
+static int grid_for(size_t total, int block = 256) {
+  size_t g = (total + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int ta_launch_dwconv(ta_ctx* ctx, const ta_dw_launch& p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * (p.C / 4);
+  if (!total) return TA_OK;
+  ta_prof_scope scope(ctx, 1, (double)total * 4 * 4 * 2);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, p);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+// ---- 2x2/2 max-pool, floor (openpose/model.py:8-13) ----------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* in, float* out, int N, int Ho, int Wo, int C,
+                                                        int in_img, int in_row, int in_pix, int in_off0,
+                                                        int out_img, int out_row, int out_pix, int out_off0) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c4);
+    size_t pix = i / c4;
+    const int x = (int)(pix % Wo);
+    pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int img = (int)(pix / Ho);
+    const float* s = in + (size_t)img * in_img + (size_t)(2 * y) * in_row + (size_t)(2 * x) * in_pix + in_off0 + cg * 4;
+    const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + in_pix);
+    const f32x4 c = *(const f32x4*)(s + in_row), d = *(const f32x4*)(s + in_row + in_pix);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *(f32x4*)(out + (size_t)img * out_img + (size_t)y * out_row + (size_t)x * out_pix + out_off0 + cg * 4) = m;
+  }
+}
+
+int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out) {
+  const size_t total = (size_t)out.n * out.h * out.w * (out.c / 4);
+  if (!total) return TA_OK;
+  ta_prof_scope scope(ctx, 1, (double)total * 16 * 5);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, out.n, out.h,
+                     out.w, out.c, (int)((size_t)in.hp() * in.wp() * in.c), in.wp() * in.c, in.c,
+                     (int)in.off(0, 0, 0), (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c, out.c,
+                     (int)out.off(0, 0, 0));
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+// ---- channel-slice copy (concat by slices, openpose/model.py:120-136) ------------------------
+__global__ __launch_bounds__(256) void copych_kernel(const float* in, float* out, int N, int H, int W, int ch,
+                                                      int in_img, int in_row, int in_pix, int in_off0,
+                                                      int out_img, int out_row, int out_pix, int out_off0) {
+  const int c4 = ch >> 2;
+  const size_t total = (size_t)N * H * W * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c4);
+    size_t pix = i / c4;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const int img = (int)(pix / H);
+    *(f32x4*)(out + (size_t)img * out_img + (size_t)y * out_row + (size_t)x * out_pix + out_off0 + cg * 4) =
+        *(const f32x4*)(in + (size_t)img * in_img + (size_t)y * in_row + (size_t)x * in_pix + in_off0 + cg * 4);
+  }
+}
+
+int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch) {
+  const size_t total = (size_t)in.n * in.h * in.w * (ch / 4);
+  if (!total) return TA_OK;
+  ta_prof_scope scope(ctx, 1, (double)total * 16 * 2);
+  hipLaunchKernelGGL(copych_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, in.n, in.h, in.w,
+                     ch, (int)((size_t)in.hp() * in.wp() * in.c), in.wp() * in.c, in.c, (int)in.off(0, 0, 0) + in_ch,
+                     (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c, out.c,
+                     (int)out.off(0, 0, 0) + out_ch);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+// ---- pre-processing --------------------------------------------------------------------------
+// RETINAFACE : NHWC RGB uint8 -> BGR float 0..255            (retinaface/wrapper.py:144-146)
+// OPENPOSE   : NHWC RGB uint8 -> RGB float x/255 - 0.5        (openpose/wrapper.py:116-122)
+// ARCFACE    : NCHW BGR uint8 crops -> BGR float (x-127.5)*0.0078125 (arcface/model.py:88)
+// Output: NHWC with 4 channels (4th = 0) in the interior of the halo-padded input tensor.
+__global__ __launch_bounds__(256) void preprocess_kernel(int mode, const uint8_t* src, int N, int H, int W,
+                                                          float* dst, int d_img, int d_row, int d_pix, int d_off0) {
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t pix = i;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const int img = (int)(pix / H);
+    f32x4 v;
+    if (mode == TA_PRE_ARCFACE_CROPS) {
+      const size_t plane = (size_t)H * W;
+      const uint8_t* s = src + (size_t)img * 3 * plane + (size_t)y * W + x;
+      v[0] = ((float)s[0] - 127.5f) * 0.0078125f;
+      v[1] = ((float)s[plane] - 127.5f) * 0.0078125f;
+      v[2] = ((float)s[2 * plane] - 127.5f) * 0.0078125f;
+    } else {
+      const uint8_t* s = src + i * 3;
+      if (mode == TA_PRE_RETINAFACE) {
+        v[0] = (float)s[2];
+        v[1] = (float)s[1];
+        v[2] = (float)s[0];
+      } else {
+        v[0] = __fdiv_rn((float)s[0], 255.0f) - 0.5f;
+        v[1] = __fdiv_rn((float)s[1], 255.0f) - 0.5f;
+        v[2] = __fdiv_rn((float)s[2], 255.0f) - 0.5f;
+      }
+    }
+    v[3] = 0.f;
+    *(f32x4*)(dst + (size_t)img * d_img + (size_t)y * d_row + (size_t)x * d_pix + d_off0) = v;
+  }
+}
+
+int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, int h, int w, const ta_tensor& dst) {
+  if (dst.c != 4 || dst.n < n || dst.h != h || dst.w != w)
+    return ta_fail(ctx, TA_E_INVALID, "preprocess: destination tensor mismatch");
+  const size_t total = (size_t)n * h * w;
+  if (!total) return TA_OK;
+  ta_prof_scope scope(ctx, 2, (double)total * (3 + 16));
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, mode, src_dev, n, h, w,
+                     dst.dev, (int)((size_t)dst.hp() * dst.wp() * dst.c), dst.wp() * dst.c, dst.c,
+                     (int)dst.off(0, 0, 0));
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}

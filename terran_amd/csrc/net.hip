@@ -1,0 +1,360 @@
+// Packed-model loader, per-shape activation planner and op-program executor.
+//
+// The op program (built by terran_amd/pack.py from a Terran state_dict) is a flat list of
+// conv / depthwise / max-pool / channel-copy ops over halo-padded NHWC tensors.  Planning for a
+// given (N,H,W) infers every tensor's spatial size, carves ONE zero-filled HBM arena (no buffer
+// reuse: 288 GB of HBM makes liveness packing pointless and the zero halos must stay intact),
+// and builds the per-conv K-offset tables.  Running is then a straight sequence of launches on
+// the context's stream.
+#include <string.h>
+
+#include "ta_internal.h"
+
+static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+static void free_plan(ta_model* m) {
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->ktab_dev) (void)hipFree(m->ktab_dev);
+  m->arena = nullptr;
+  m->ktab_dev = nullptr;
+  m->arena_bytes = 0;
+  m->plan_n = m->plan_h = m->plan_w = 0;
+  m->tensors.clear();
+}
+
+int ta_model_plan(ta_model* m, int n, int h, int w) {
+  ta_ctx* ctx = m->ctx;
+  if (n <= 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "plan: bad input shape %dx%dx%d", n, h, w);
+  if (m->plan_n == n && m->plan_h == h && m->plan_w == w) return TA_OK;
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_plan(m);
+
+  const int T = m->hdr.n_tensors;
+  std::vector<ta_tensor> ts(T);
+  std::vector<bool> set(T, false);
+  for (int i = 0; i < T; ++i) {
+    ts[i].c = m->tdesc[i].channels;
+    ts[i].halo = m->tdesc[i].halo;
+    ts[i].n = n;
+  }
+  const int in_id = m->hdr.input_tensor;
+  ts[in_id].h = h;
+  ts[in_id].w = w;
+  set[in_id] = true;
+
+  auto resolve_alias = [&](int id) -> int {
+    const int src = m->tdesc[id].alias_of;
+    if (src < 0 || set[id]) return TA_OK;
+    if (!set[src]) return ta_fail(ctx, TA_E_INVALID, "plan: alias tensor %d used before its source %d", id, src);
+    if (ts[src].halo != 0 || (size_t)ts[src].h * ts[src].w * ts[src].c != (size_t)ts[id].c)
+      return ta_fail(ctx, TA_E_INVALID, "plan: alias tensor %d does not match source %d", id, src);
+    ts[id].h = ts[id].w = 1;
+    ts[id].owns = false;
+    set[id] = true;
+    return TA_OK;
+  };
+
+  auto set_out = [&](int id, int oh, int ow) -> int {
+    if (oh <= 0 || ow <= 0) return ta_fail(ctx, TA_E_INVALID, "plan: input %dx%d too small for the network", h, w);
+    if (set[id]) {
+      if (ts[id].h != oh || ts[id].w != ow)
+        return ta_fail(ctx, TA_E_INVALID, "plan: tensor %d written with %dx%d and %dx%d", id, ts[id].h, ts[id].w, oh, ow);
+      return TA_OK;
+    }
+    ts[id].h = oh;
+    ts[id].w = ow;
+    set[id] = true;
+    return TA_OK;
+  };
+
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const ta_op_desc& op = m->ops[oi];
+    TA_TRY(resolve_alias(op.in));
+    if (!set[op.in]) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu reads unset tensor %d", oi, op.in);
+    const ta_tensor& ti = ts[op.in];
+    switch (op.type) {
+      case TA_OP_CONV:
+      case TA_OP_DWCONV:
+        if (ti.halo < op.pad) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu needs halo %d, tensor has %d", oi, op.pad, ti.halo);
+        TA_TRY(set_out(op.out, conv_out(ti.h, op.kh, op.stride, op.pad), conv_out(ti.w, op.kw, op.stride, op.pad)));
+        if (op.out2 >= 0) TA_TRY(set_out(op.out2, ts[op.out].h, ts[op.out].w));
+        break;
+      case TA_OP_MAXPOOL:
+        TA_TRY(set_out(op.out, ti.h / 2, ti.w / 2));
+        break;
+      case TA_OP_COPYCH:
+        TA_TRY(set_out(op.out, ti.h, ti.w));
+        break;
+      default:
+        return ta_fail(ctx, TA_E_INVALID, "plan: unknown op type %d", op.type);
+    }
+  }
+  for (int i = 0; i < T; ++i) TA_TRY(resolve_alias(i));
+
+  // carve the arena
+  size_t total = 0;
+  std::vector<size_t> offs(T, 0);
+  for (int i = 0; i < T; ++i) {
+    if (!set[i] || !ts[i].owns) continue;
+    const size_t bytes = ts[i].elems() * sizeof(float);
+    if (bytes >= ((size_t)1 << 32)) return ta_fail(ctx, TA_E_INVALID, "plan: tensor %d exceeds 4 GiB; split the batch", i);
+    offs[i] = total;
+    total += (bytes + 255) & ~(size_t)255;
+  }
+  hipError_t e = hipMalloc((void**)&m->arena, total ? total : 256);
+  if (e != hipSuccess) return ta_fail(ctx, TA_E_DEVICE, "plan: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+  m->arena_bytes = total;
+  TA_HIP(ctx, hipMemsetAsync(m->arena, 0, total ? total : 256, ctx->stream));
+  for (int i = 0; i < T; ++i)
+    if (set[i] && ts[i].owns) ts[i].dev = (float*)(m->arena + offs[i]);
+  for (int i = 0; i < T; ++i)
+    if (set[i] && !ts[i].owns) ts[i].dev = ts[m->tdesc[i].alias_of].dev;
+
+  // K-offset tables
+  std::vector<int32_t> ktab;
+  m->ktab_off.assign(m->ops.size(), 0);
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const ta_op_desc& op = m->ops[oi];
+    if (op.type != TA_OP_CONV) continue;
+    const ta_tensor& ti = ts[op.in];
+    m->ktab_off[oi] = ktab.size();
+    const int cpt = op.cin / 4;
+    const int nq = op.kh * op.kw * cpt;
+    if (nq > op.n_slabs * 8) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu has too few K slabs", oi);
+    for (int q = 0; q < op.n_slabs * 8; ++q) {
+      int32_t off = 0;
+      if (q < nq) {
+        const int tap = q / cpt, ch = (q % cpt) * 4;
+        const int ky = tap / op.kw, kx = tap % op.kw;
+        off = (int32_t)((((size_t)ky * ti.wp() + kx) * ti.c + op.in_ch_off + ch) * sizeof(float));
+      }
+      ktab.push_back(off);
+    }
+  }
+  if (!ktab.empty()) {
+    TA_HIP(ctx, hipMalloc((void**)&m->ktab_dev, ktab.size() * sizeof(int32_t)));
+    TA_HIP(ctx, hipMemcpy(m->ktab_dev, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  m->tensors.swap(ts);
+  m->plan_n = n;
+  m->plan_h = h;
+  m->plan_w = w;
+  return TA_OK;
+}
+
+static const float* wptr(const ta_model* m, int64_t off) { return off < 0 ? nullptr : (const float*)(m->weights_dev + off); }
+
+int ta_model_run_ops(ta_model* m) {
+  ta_ctx* ctx = m->ctx;
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const ta_op_desc& op = m->ops[oi];
+    const ta_tensor& ti = m->tensors[op.in];
+    const ta_tensor& to = m->tensors[op.out];
+    switch (op.type) {
+      case TA_OP_CONV: {
+        ta_conv_launch p;
+        memset(&p, 0, sizeof(p));
+        p.in = ti.dev;
+        p.w = wptr(m, op.w_off);
+        p.ktab = m->ktab_dev + m->ktab_off[oi];
+        p.bias = wptr(m, op.bias_off);
+        p.prelu = wptr(m, op.prelu_off);
+        p.out = to.dev;
+        p.M = to.n * to.h * to.w;
+        p.Ho = to.h;
+        p.Wo = to.w;
+        p.n_slabs = op.n_slabs;
+        p.coutp = op.coutp;
+        p.cout = op.cout;
+        p.act = op.act;
+        p.stride = op.stride;
+        p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
+        p.in_row = ti.wp() * ti.c;
+        p.in_pix = ti.c;
+        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.c);
+        p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
+        p.out_row = to.wp() * to.c;
+        p.out_pix = to.c;
+        p.out_off0 = (int)to.off(0, 0, 0) + op.out_ch_off;
+        if (op.res >= 0) {
+          const ta_tensor& tr = m->tensors[op.res];
+          p.res = tr.dev;
+          p.res_img = (int)((size_t)tr.hp() * tr.wp() * tr.c);
+          p.res_row = tr.wp() * tr.c;
+          p.res_pix = tr.c;
+          p.res_off0 = (int)tr.off(0, 0, 0) + op.res_ch_off;
+          p.res_up2 = op.res_up2;
+        }
+        if (op.out2 >= 0) {
+          const ta_tensor& t2 = m->tensors[op.out2];
+          p.out2 = t2.dev;
+          p.scale2 = wptr(m, op.scale2_off);
+          p.shift2 = wptr(m, op.shift2_off);
+          p.o2_img = (int)((size_t)t2.hp() * t2.wp() * t2.c);
+          p.o2_row = t2.wp() * t2.c;
+          p.o2_pix = t2.c;
+          p.o2_off0 = (int)t2.off(0, 0, 0) + op.out2_ch_off;
+        }
+        TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
+        break;
+      }
+      case TA_OP_DWCONV: {
+        ta_dw_launch p;
+        memset(&p, 0, sizeof(p));
+        p.in = ti.dev;
+        p.w = wptr(m, op.w_off);
+        p.bias = wptr(m, op.bias_off);
+        p.out = to.dev;
+        p.N = to.n;
+        p.Ho = to.h;
+        p.Wo = to.w;
+        p.C = op.cin;
+        p.stride = op.stride;
+        p.relu = op.act == TA_ACT_RELU;
+        p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
+        p.in_row = ti.wp() * ti.c;
+        p.in_pix = ti.c;
+        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.c) + op.in_ch_off;
+        p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
+        p.out_row = to.wp() * to.c;
+        p.out_pix = to.c;
+        p.out_off0 = (int)to.off(0, 0, 0) + op.out_ch_off;
+        TA_TRY(ta_launch_dwconv(ctx, p));
+        break;
+      }
+      case TA_OP_MAXPOOL:
+        TA_TRY(ta_launch_maxpool(ctx, ti, to));
+        break;
+      case TA_OP_COPYCH:
+        TA_TRY(ta_launch_copych(ctx, ti, op.in_ch_off, to, op.out_ch_off, op.cin));
+        break;
+    }
+  }
+  return TA_OK;
+}
+
+extern "C" {
+
+int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_model** out) {
+  if (!ctx || !blob || !out) return TA_E_INVALID;
+  *out = nullptr;
+  if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
+  ta_blob_header h;
+  memcpy(&h, blob, sizeof(h));
+  if (h.magic != TA_BLOB_MAGIC || h.version != 1) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
+  if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
+      h.input_tensor >= h.n_tensors)
+    return ta_fail(ctx, TA_E_INVALID, "model blob: bad counts");
+  const size_t t_end = (size_t)h.tensors_off + (size_t)h.n_tensors * sizeof(ta_tensor_desc);
+  const size_t o_end = (size_t)h.ops_off + (size_t)h.n_ops * sizeof(ta_op_desc);
+  const size_t w_end = (size_t)h.weights_off + (size_t)h.weights_bytes;
+  if (t_end > bytes || o_end > bytes || w_end > bytes) return ta_fail(ctx, TA_E_INVALID, "model blob: truncated");
+  ta_model* m = new ta_model();
+  m->ctx = ctx;
+  m->kind = kind;
+  m->hdr = h;
+  m->tdesc.resize(h.n_tensors);
+  m->ops.resize(h.n_ops);
+  memcpy(m->tdesc.data(), (const char*)blob + h.tensors_off, h.n_tensors * sizeof(ta_tensor_desc));
+  memcpy(m->ops.data(), (const char*)blob + h.ops_off, h.n_ops * sizeof(ta_op_desc));
+  for (auto& op : m->ops) {
+    auto bad_t = [&](int t) { return t < 0 || t >= h.n_tensors; };
+    auto bad_w = [&](int64_t off, size_t need) { return off >= 0 && (size_t)off + need > (size_t)h.weights_bytes; };
+    bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
+    if (op.type == TA_OP_CONV) {
+      bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
+            op.stride <= 0 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
+            bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
+            (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0));
+    } else if (op.type == TA_OP_DWCONV) {
+      bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.kh != 3 || op.kw != 3 ||
+            bad_w(op.w_off, (size_t)op.cin * 36) || bad_w(op.bias_off, (size_t)op.cin * 4);
+    }
+    if (bad) {
+      delete m;
+      return ta_fail(ctx, TA_E_INVALID, "model blob: malformed op");
+    }
+  }
+  hipError_t e = hipMalloc((void**)&m->weights_dev, h.weights_bytes ? h.weights_bytes : 16);
+  if (e != hipSuccess) {
+    delete m;
+    return ta_fail(ctx, TA_E_DEVICE, "hipMalloc(weights %lld) failed: %s", (long long)h.weights_bytes, hipGetErrorString(e));
+  }
+  e = hipMemcpy(m->weights_dev, (const char*)blob + h.weights_off, h.weights_bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(m->weights_dev);
+    delete m;
+    return ta_fail(ctx, TA_E_DEVICE, "weights upload failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return TA_OK;
+}
+
+void ta_model_free(ta_model* m) {
+  if (!m) return;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  free_plan(m);
+  if (m->weights_dev) (void)hipFree(m->weights_dev);
+  delete m;
+}
+
+int ta_model_kind(const ta_model* m) { return m ? m->kind : TA_E_INVALID; }
+
+int ta_model_forward_frames(ta_model* m, const ta_frames* f) {
+  if (!m || !f) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  if (m->kind != TA_MODEL_RETINAFACE && m->kind != TA_MODEL_OPENPOSE)
+    return ta_fail(ctx, TA_E_INVALID, "forward_frames: model kind %d takes crops", m->kind);
+  if (f->n == 0) return TA_OK;
+  TA_TRY(ta_model_plan(m, f->n, f->h, f->w));
+  TA_TRY(ta_launch_preprocess(ctx, m->kind == TA_MODEL_RETINAFACE ? TA_PRE_RETINAFACE : TA_PRE_OPENPOSE, f->dev, f->n,
+                              f->h, f->w, m->tensors[m->hdr.input_tensor]));
+  return ta_model_run_ops(m);
+}
+
+int ta_model_forward_crops(ta_model* m, const uint8_t* crops, int n) {
+  if (!m || (!crops && n > 0)) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  if (m->kind != TA_MODEL_ARCFACE) return ta_fail(ctx, TA_E_INVALID, "forward_crops: not an ArcFace model");
+  if (n == 0) return TA_OK;
+  TA_TRY(ta_model_plan(m, n, 112, 112));
+  void* scr = nullptr;
+  const size_t bytes = (size_t)n * 3 * 112 * 112;
+  TA_TRY(ta_scratch(ctx, bytes, &scr));
+  TA_HIP(ctx, hipMemcpyAsync(scr, crops, bytes, hipMemcpyHostToDevice, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TA_TRY(ta_launch_preprocess(ctx, TA_PRE_ARCFACE_CROPS, (const uint8_t*)scr, n, 112, 112,
+                              m->tensors[m->hdr.input_tensor]));
+  return ta_model_run_ops(m);
+}
+
+int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* w) {
+  if (!m || tensor < 0 || tensor >= (int)m->tensors.size()) return TA_E_INVALID;
+  const ta_tensor& t = m->tensors[tensor];
+  if (n) *n = t.n;
+  if (c) *c = t.c;
+  if (h) *h = t.h;
+  if (w) *w = t.w;
+  return TA_OK;
+}
+
+int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst) {
+  if (!m || !dst || tensor < 0 || tensor >= (int)m->tensors.size()) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  const ta_tensor& t = m->tensors[tensor];
+  if (!t.dev || ch_off < 0 || ch <= 0 || ch_off + ch > t.c) return ta_fail(ctx, TA_E_INVALID, "read_tensor: bad slice");
+  std::vector<float> host(t.elems());
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TA_HIP(ctx, hipMemcpy(host.data(), t.dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int i = 0; i < t.n; ++i)
+    for (int c = 0; c < ch; ++c)
+      for (int y = 0; y < t.h; ++y)
+        for (int x = 0; x < t.w; ++x)
+          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = host[t.off(i, y, x) + ch_off + c];
+  return TA_OK;
+}
+
+}  // extern "C"

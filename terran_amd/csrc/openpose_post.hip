@@ -1,0 +1,665 @@
+// OpenPose post-processing on the device (pose/openpose/wrapper.py:214-485):
+//   1. x8 bicubic upsample of the 38 PAF + 19 heat-map channels (A=-0.75, align_corners=False,
+//      no output clamp), tap accumulation in the exact order torch's CPU kernel uses:
+//      fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1))) horizontally on 4 rows, then vertically;
+//   2. peak finding on parts 0..17: interior pixels, >= the 4 neighbours and >= 0.1, row-major
+//      ordered compaction (ballot prefix sums), one workgroup per (image, part);
+//   3. PAF line-integral scoring of every (src, dst) peak pair of a limb (10 truncated linspace
+//      samples, length penalty, >=9 samples > 0.05 and score > 0), ordered compaction of the
+//      accepted pairs, bitonic sort by descending score (ties: row-major pair order) and the
+//      reference's greedy matching with its single shared `seen` set -- one workgroup per
+//      (image, limb);
+//   4. person assembly, filtering and keypoint output -- one wavefront per image, the search for
+//      matching humans done lane-parallel, scores accumulated in float64 like the reference.
+// Compiled with -ffp-contract=off; every float32 step rounds once, as oracle/openpose_post.py does.
+#include <math.h>
+#include <string.h>
+
+#include "ta_internal.h"
+
+#define OP_MAXP 1024       // peaks per (image, part)
+#define OP_MAXC 8192       // accepted pair candidates per (image, limb)
+#define OP_MAXH 192        // humans under assembly per image
+#define OP_NMID 10
+
+__constant__ int c_map_idx[19][2] = {{31, 32}, {39, 40}, {33, 34}, {35, 36}, {41, 42}, {43, 44}, {19, 20}, {21, 22},
+                                      {23, 24}, {25, 26}, {27, 28}, {29, 30}, {47, 48}, {49, 50}, {53, 54}, {51, 52},
+                                      {55, 56}, {37, 38}, {45, 46}};
+__constant__ int c_limbseq[19][2] = {{2, 3}, {2, 6}, {3, 4}, {4, 5}, {6, 7}, {7, 8}, {2, 9}, {9, 10}, {10, 11}, {2, 12},
+                                      {12, 13}, {13, 14}, {2, 1}, {1, 15}, {15, 17}, {1, 16}, {16, 18}, {3, 17}, {6, 18}};
+
+struct op_maps {
+  const float* base;      // network-resolution maps, NHWC-like addressing
+  int img, row, pix;      // element strides
+  int paf_off, hm_off;    // element offset of PAF channel 0 / heat-map channel 0 (incl. halo offset)
+  int h, w;
+};
+
+// ---- 1. bicubic x8 ------------------------------------------------------------------------------
+// up: [N][57][8h][8w] planar; channel c<38 = PAF c, c>=38 = heat-map c-38.
+__global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, float* up, const int* ytab, const float* ywt,
+                                                       const int* xtab, const float* xwt) {
+  const int H8 = m.h * 8, W8 = m.w * 8;
+  const size_t total = (size_t)N * 57 * H8 * W8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W8);
+    size_t r = i / W8;
+    const int y = (int)(r % H8);
+    r /= H8;
+    const int c = (int)(r % 57);
+    const int img = (int)(r / 57);
+    const float* src = m.base + (size_t)img * m.img + (c < 38 ? m.paf_off + c : m.hm_off + (c - 38));
+    const int4 xi = *(const int4*)(xtab + 4 * x);
+    const float4 xw = *(const float4*)(xwt + 4 * x);
+    const int4 yi = *(const int4*)(ytab + 4 * y);
+    const float4 yw = *(const float4*)(ywt + 4 * y);
+    const int ys[4] = {yi.x, yi.y, yi.z, yi.w};
+    float rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* rp = src + (size_t)ys[k] * m.row;
+      const float v0 = rp[(size_t)xi.x * m.pix], v1 = rp[(size_t)xi.y * m.pix];
+      const float v2 = rp[(size_t)xi.z * m.pix], v3 = rp[(size_t)xi.w * m.pix];
+      float a = v1 * xw.y;
+      a = __builtin_fmaf(v0, xw.x, a);
+      a = __builtin_fmaf(v2, xw.z, a);
+      a = __builtin_fmaf(v3, xw.w, a);
+      rows[k] = a;
+    }
+    float o = rows[1] * yw.y;
+    o = __builtin_fmaf(rows[0], yw.x, o);
+    o = __builtin_fmaf(rows[2], yw.z, o);
+    o = __builtin_fmaf(rows[3], yw.w, o);
+    up[i] = o;
+  }
+}
+
+static void cubic_axis(int in_size, std::vector<int>& idx, std::vector<float>& wts) {
+  // mirrors oracle/openpose_post.py:_axis_plan / cubic_coeffs (ATen area_pixel_compute_source_index +
+  // get_cubic_upsample_coefficients, A = -0.75); all values are exact in float32.
+  const int out = in_size * 8;
+  idx.resize((size_t)out * 4);
+  wts.resize((size_t)out * 4);
+  const float A = -0.75f;
+  auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+  auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+  for (int d = 0; d < out; ++d) {
+    const float real = 0.125f * ((float)d + 0.5f) - 0.5f;
+    const float fl = floorf(real);
+    const float t = real - fl;
+    const int i0 = (int)fl;
+    for (int k = 0; k < 4; ++k) {
+      int v = i0 - 1 + k;
+      v = v < 0 ? 0 : (v > in_size - 1 ? in_size - 1 : v);
+      idx[(size_t)d * 4 + k] = v;
+    }
+    const float x2 = 1.f - t;
+    wts[(size_t)d * 4 + 0] = c2(t + 1.f);
+    wts[(size_t)d * 4 + 1] = c1(t);
+    wts[(size_t)d * 4 + 2] = c1(x2);
+    wts[(size_t)d * 4 + 3] = c2(x2 + 1.f);
+  }
+}
+
+// ---- 2. peaks -------------------------------------------------------------------------------------
+struct op_work {
+  const float* up;     // [N][57][H8][W8]
+  int N, H8, W8;
+  int* peak_cnt;       // [N][18]
+  int* peak_yx;        // [N][18][OP_MAXP][2]
+  float* peak_sc;      // [N][18][OP_MAXP]
+  int* conn_cnt;       // [N][19]   (-1 = limb missing)
+  int* conn_ij;        // [N][19][OP_MAXP][2]
+  float* conn_sc;      // [N][19][OP_MAXP]
+  unsigned long long* cand;   // [N][19][OP_MAXC] sort keys
+  int* overflow;       // [1] sticky flag
+  double scale;
+  int* out_cnt;        // [N]
+  int* out_kp;         // [N][OP_MAXH][18][3]
+  double* out_sc;      // [N][OP_MAXH]
+};
+
+__global__ __launch_bounds__(1024) void peaks_kernel(const op_work w) {
+  __shared__ int wave_tot[16];
+  __shared__ int s_base;
+  const int part = blockIdx.x % 18, img = blockIdx.x / 18;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* m = w.up + ((size_t)img * 57 + 38 + part) * w.H8 * w.W8;
+  const int ih = w.H8 - 2, iw = w.W8 - 2;
+  const int total = ih > 0 && iw > 0 ? ih * iw : 0;
+  int* yx = w.peak_yx + ((size_t)img * 18 + part) * OP_MAXP * 2;
+  float* sc = w.peak_sc + ((size_t)img * 18 + part) * OP_MAXP;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < total; t0 += 1024) {
+    const int t = t0 + tid;
+    bool pk = false;
+    float v = 0.f;
+    int y = 0, x = 0;
+    if (t < total) {
+      y = t / iw + 1;
+      x = t - (y - 1) * iw + 1;
+      const float* p = m + (size_t)y * w.W8 + x;
+      v = p[0];
+      pk = (v >= p[-w.W8]) && (v >= p[-1]) && (v >= p[w.W8]) && (v >= p[1]) && (v >= 0.1f);
+    }
+    const unsigned long long bal = __ballot(pk);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    if (pk) {
+      const int pos = off + before;
+      if (pos < OP_MAXP) {
+        yx[pos * 2] = y;
+        yx[pos * 2 + 1] = x;
+        sc[pos] = v;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int k = 0; k < 16; ++k) tot += wave_tot[k];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int c = s_base;
+    if (c > OP_MAXP) {
+      atomicExch(w.overflow, 1);
+      c = OP_MAXP;
+    }
+    w.peak_cnt[img * 18 + part] = c;
+  }
+}
+
+// ---- 3. limb scoring + greedy matching --------------------------------------------------------------
+__device__ __forceinline__ int lin_trunc(float a, float b, float step, int i) {
+  const float v = i < OP_NMID / 2 ? a + step * (float)i : b - step * (float)(OP_NMID - 1 - i);
+  return (int)truncf(v);
+}
+
+__global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;               // OP_MAXC
+  unsigned* seen = (unsigned*)(smem + (size_t)OP_MAXC * 8);           // OP_MAXP bits
+  int* wave_tot = (int*)(seen + OP_MAXP / 32);                        // 4 + 1
+  int& s_base = wave_tot[4];
+
+  const int limb = blockIdx.x % 19, img = blockIdx.x / 19;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ks = c_limbseq[limb][0] - 1, kd = c_limbseq[limb][1] - 1;
+  const int ns = w.peak_cnt[img * 18 + ks], nd = w.peak_cnt[img * 18 + kd];
+  int* conn_ij = w.conn_ij + ((size_t)img * 19 + limb) * OP_MAXP * 2;
+  float* conn_sc = w.conn_sc + ((size_t)img * 19 + limb) * OP_MAXP;
+  if (ns == 0 || nd == 0) {
+    if (tid == 0) w.conn_cnt[img * 19 + limb] = -1;     // "missing limb" (wrapper.py:293-296)
+    return;
+  }
+  const int* syx = w.peak_yx + ((size_t)img * 18 + ks) * OP_MAXP * 2;
+  const int* dyx = w.peak_yx + ((size_t)img * 18 + kd) * OP_MAXP * 2;
+  const size_t plane = (size_t)w.H8 * w.W8;
+  const float* pafx = w.up + ((size_t)img * 57 + (c_map_idx[limb][0] - 19)) * plane;
+  const float* pafy = w.up + ((size_t)img * 57 + (c_map_idx[limb][1] - 19)) * plane;
+  const float half_h = (float)(0.5 * (double)w.H8);
+
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int total = ns * nd;
+  for (int t0 = 0; t0 < total; t0 += 256) {
+    const int t = t0 + tid;
+    bool ok = false;
+    float reg = 0.f;
+    if (t < total) {
+      const int i = t / nd, j = t - i * nd;
+      const int sy = syx[i * 2], sx = syx[i * 2 + 1], ty = dyx[j * 2], tx = dyx[j * 2 + 1];
+      const float dyf = (float)(ty - sy), dxf = (float)(tx - sx);
+      const float norm = __fsqrt_rn(dyf * dyf + dxf * dxf);
+      const float uy = __fdiv_rn(dyf, norm), ux = __fdiv_rn(dxf, norm);
+      const float ay = (float)sy, by = (float)ty, ax = (float)sx, bx = (float)tx;
+      const float stepy = __fdiv_rn(by - ay, (float)(OP_NMID - 1)), stepx = __fdiv_rn(bx - ax, (float)(OP_NMID - 1));
+      float tot = 0.f;
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < OP_NMID; ++k) {
+        const int yy = lin_trunc(ay, by, stepy, k), xx = lin_trunc(ax, bx, stepx, k);
+        const size_t o = (size_t)yy * w.W8 + xx;
+        const float mid = pafx[o] * ux + pafy[o] * uy;
+        tot = k == 0 ? mid : tot + mid;
+        cnt += mid > 0.05f ? 1 : 0;
+      }
+      const float pen = fminf(__fdiv_rn(half_h, norm) - 1.0f, 0.0f);
+      reg = __fdiv_rn(tot, (float)OP_NMID) + pen;
+      ok = (cnt > 8) && (reg > 0.0f);
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    if (ok) {
+      const int pos = off + before;
+      if (pos < OP_MAXC) keys[pos] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(reg)) << 32) | (unsigned)t;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  int C = s_base;
+  if (C > OP_MAXC) {
+    if (tid == 0) atomicExch(w.overflow, 1);
+    C = OP_MAXC;
+  }
+  int P = 1;
+  while (P < C) P <<= 1;
+  for (int i = C + tid; i < P; i += 256) keys[i] = ~0ull;
+  for (int i = tid; i < OP_MAXP / 32; i += 256) seen[i] = 0;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          if ((a > b) == ((i & k) == 0)) {
+            keys[i] = b;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // greedy matching (wrapper.py:335-359): ONE `seen` set for source and destination indices; the
+  // length check precedes the insertions.
+  if (tid == 0) {
+    const int lim = ns < nd ? ns : nd;
+    int n = 0;
+    for (int c = 0; c < C; ++c) {
+      const unsigned long long key = keys[c];
+      const int t = (int)(unsigned)(key & 0xFFFFFFFFull);
+      const int i = t / nd, j = t - i * nd;
+      if (((seen[i >> 5] >> (i & 31)) & 1u) || ((seen[j >> 5] >> (j & 31)) & 1u)) continue;
+      conn_ij[n * 2] = i;
+      conn_ij[n * 2 + 1] = j;
+      conn_sc[n] = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
+      ++n;
+      if (n >= lim) break;
+      seen[i >> 5] |= 1u << (i & 31);
+      seen[j >> 5] |= 1u << (j & 31);
+    }
+    w.conn_cnt[img * 19 + limb] = n;
+  }
+}
+
+// ---- 4. assembly -------------------------------------------------------------------------------------
+// humans[h][0..17] = global peak id or -1; [18] = score sum; [19] = keypoint count (all float64, as the
+// reference's numpy array).  One wavefront per image; lane-parallel search for matching humans.
+__global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
+  __shared__ double humans[OP_MAXH][20];
+  __shared__ int offs[19];
+  const int img = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) {
+    int o = 0;
+    for (int p = 0; p < 18; ++p) {
+      offs[p] = o;
+      o += w.peak_cnt[img * 18 + p];
+    }
+    offs[18] = o;
+  }
+  __syncthreads();
+  int nh = 0;
+  bool over = false;
+  for (int limb = 0; limb < 19; ++limb) {
+    const int nc = w.conn_cnt[img * 19 + limb];
+    if (nc < 0) continue;
+    const int ks = c_limbseq[limb][0] - 1, kd = c_limbseq[limb][1] - 1;
+    const int* cij = w.conn_ij + ((size_t)img * 19 + limb) * OP_MAXP * 2;
+    const float* csc = w.conn_sc + ((size_t)img * 19 + limb) * OP_MAXP;
+    const float* psc_d = w.peak_sc + ((size_t)img * 18 + kd) * OP_MAXP;
+    const float* psc_s = w.peak_sc + ((size_t)img * 18 + ks) * OP_MAXP;
+    for (int c = 0; c < nc; ++c) {
+      const int i = cij[c * 2], j = cij[c * 2 + 1];
+      const double a = (double)(offs[ks] + i), b = (double)(offs[kd] + j);
+      const double s = (double)csc[c];
+      const double peak_b = (double)psc_d[j];
+      // matched humans in ascending index order (up to two matter)
+      int first = -1, second = -1, nmatch = 0;
+      for (int h0 = 0; h0 < nh; h0 += 64) {
+        const int h = h0 + lane;
+        const bool mt = h < nh && (humans[h][ks] == a || humans[h][kd] == b);
+        unsigned long long bal = __ballot(mt);
+        while (bal) {
+          const int l = __ffsll((long long)bal) - 1;
+          bal &= bal - 1;
+          if (nmatch == 0) first = h0 + l;
+          else if (nmatch == 1) second = h0 + l;
+          ++nmatch;
+        }
+      }
+      if (nmatch == 1) {
+        if (lane == 0 && humans[first][kd] != b) {
+          humans[first][kd] = b;
+          humans[first][19] += 1.0;
+          humans[first][18] += peak_b + s;
+        }
+      } else if (nmatch == 2) {
+        bool overlap = false;
+        if (lane < 18) overlap = humans[first][lane] >= 0.0 && humans[second][lane] >= 0.0;
+        const bool any = __ballot(overlap) != 0ull;
+        if (!any) {
+          if (lane < 18) humans[first][lane] += humans[second][lane] + 1.0;
+          if (lane == 18) humans[first][18] = (humans[first][18] + humans[second][18]) + s;
+          if (lane == 19) humans[first][19] += humans[second][19];
+          __syncthreads();
+          // np.delete(humans, second): shift the tail down by one row
+          for (int h = second; h + 1 < nh; ++h) {
+            double v = 0.0;
+            if (lane < 20) v = humans[h + 1][lane];
+            __syncthreads();
+            if (lane < 20) humans[h][lane] = v;
+            __syncthreads();
+          }
+          --nh;
+        } else if (lane == 0) {
+          humans[first][kd] = b;
+          humans[first][19] += 1.0;
+          humans[first][18] += peak_b + s;
+        }
+      } else if (nmatch == 0 && limb < 17) {
+        if (nh < OP_MAXH) {
+          if (lane < 18) humans[nh][lane] = -1.0;
+          __syncthreads();
+          if (lane == 0) {
+            humans[nh][ks] = a;
+            humans[nh][kd] = b;
+            humans[nh][19] = 2.0;
+            humans[nh][18] = ((0.0 + (double)psc_s[i]) + peak_b) + s;
+          }
+          ++nh;
+        } else {
+          over = true;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (over && lane == 0) atomicExch(w.overflow, 1);
+  // filter + keypoints (wrapper.py:470-483, 37-90)
+  int kept = 0;
+  for (int h = 0; h < nh; ++h) {
+    const double cnt = humans[h][19], tot = humans[h][18];
+    if (cnt < 4.0 || tot / cnt < 0.4) continue;
+    int* kp = w.out_kp + ((size_t)img * OP_MAXH + kept) * 54;
+    if (lane < 18) {
+      const double pid = humans[h][lane];
+      int x = 0, y = 0, pr = 0;
+      if ((int)pid != -1) {
+        const int id = (int)pid;
+        int part = 0;
+        while (part < 17 && id >= offs[part + 1]) ++part;
+        const int* yx = w.peak_yx + (((size_t)img * 18 + part) * OP_MAXP + (id - offs[part])) * 2;
+        y = (int)((double)yx[0] / w.scale);
+        x = (int)((double)yx[1] / w.scale);
+        pr = 1;
+      }
+      kp[lane * 3] = x;
+      kp[lane * 3 + 1] = y;
+      kp[lane * 3 + 2] = pr;
+    }
+    if (lane == 0) w.out_sc[(size_t)img * OP_MAXH + kept] = tot / cnt;
+    ++kept;
+  }
+  if (lane == 0) w.out_cnt[img] = kept;
+}
+
+__global__ __launch_bounds__(256) void op_gather_kernel(const op_work w, int* o_kp, double* o_sc) {
+  const int img = blockIdx.x;
+  int base = 0;
+  for (int i = 0; i < img; ++i) base += w.out_cnt[i];
+  const int K = w.out_cnt[img];
+  for (int t = threadIdx.x; t < K * 54; t += blockDim.x) o_kp[(size_t)base * 54 + t] = w.out_kp[(size_t)img * OP_MAXH * 54 + t];
+  for (int t = threadIdx.x; t < K; t += blockDim.x) o_sc[base + t] = w.out_sc[(size_t)img * OP_MAXH + t];
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int upload_axis_tables(ta_ctx* ctx, int h, int w, char* dev, size_t* sizes) {
+  std::vector<int> yi, xi;
+  std::vector<float> yw, xw;
+  cubic_axis(h, yi, yw);
+  cubic_axis(w, xi, xw);
+  void* pin = nullptr;
+  const size_t by = yi.size() * 4, bx = xi.size() * 4;
+  TA_TRY(ta_pinned(ctx, 2 * (by + bx), &pin));
+  char* p = (char*)pin;
+  memcpy(p, yi.data(), by);
+  memcpy(p + by, yw.data(), by);
+  memcpy(p + 2 * by, xi.data(), bx);
+  memcpy(p + 2 * by + bx, xw.data(), bx);
+  TA_HIP(ctx, hipMemcpyAsync(dev, pin, 2 * (by + bx), hipMemcpyHostToDevice, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sizes[0] = by;
+  sizes[1] = bx;
+  return TA_OK;
+}
+
+static size_t rup256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// maps -> packed results on the host.  `up_out` (optional) receives the upsampled maps instead of grouping.
+static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale, int capacity, int32_t* counts,
+                              int32_t* keypoints, double* scores, int32_t* required, float* up_out_host) {
+  const int H8 = m.h * 8, W8 = m.w * 8;
+  const size_t up_bytes = rup256((size_t)N * 57 * H8 * W8 * 4);
+  const size_t tab_bytes = rup256((size_t)(H8 + W8) * 32);
+  size_t off = 0;
+  auto carve = [&](size_t b) {
+    size_t o = off;
+    off += rup256(b);
+    return o;
+  };
+  const size_t o_up = carve(up_bytes), o_tab = carve(tab_bytes);
+  const size_t o_pcnt = carve((size_t)N * 18 * 4), o_pyx = carve((size_t)N * 18 * OP_MAXP * 8), o_psc = carve((size_t)N * 18 * OP_MAXP * 4);
+  const size_t o_ccnt = carve((size_t)N * 19 * 4), o_cij = carve((size_t)N * 19 * OP_MAXP * 8), o_csc = carve((size_t)N * 19 * OP_MAXP * 4);
+  const size_t o_ovf = carve(256), o_ocnt = carve((size_t)N * 4), o_okp = carve((size_t)N * OP_MAXH * 54 * 4), o_osc = carve((size_t)N * OP_MAXH * 8);
+  const size_t cap = capacity > 0 ? (size_t)capacity : 0;
+  const size_t o_gkp = carve(cap * 54 * 4), o_gsc = carve(cap * 8);
+  char* scr = nullptr;
+  TA_TRY(ta_scratch(ctx, off, (void**)&scr));
+  size_t ts[2];
+  TA_TRY(upload_axis_tables(ctx, m.h, m.w, scr + o_tab, ts));
+  const int* ytab = (const int*)(scr + o_tab);
+  const float* ywt = (const float*)(scr + o_tab + ts[0]);
+  const int* xtab = (const int*)(scr + o_tab + 2 * ts[0]);
+  const float* xwt = (const float*)(scr + o_tab + 2 * ts[0] + ts[1]);
+  float* up = (float*)(scr + o_up);
+  {
+    const size_t total = (size_t)N * 57 * H8 * W8;
+    ta_prof_scope scope(ctx, 3, (double)total * 4);
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(bicubic_kernel, dim3((int)g), dim3(256), 0, ctx->stream, m, N, up, ytab, ywt, xtab, xwt);
+    TA_HIP(ctx, hipGetLastError());
+  }
+  if (up_out_host) {
+    TA_HIP(ctx, hipMemcpyAsync(up_out_host, up, (size_t)N * 57 * H8 * W8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TA_OK;
+  }
+  op_work w;
+  memset(&w, 0, sizeof(w));
+  w.up = up;
+  w.N = N;
+  w.H8 = H8;
+  w.W8 = W8;
+  w.peak_cnt = (int*)(scr + o_pcnt);
+  w.peak_yx = (int*)(scr + o_pyx);
+  w.peak_sc = (float*)(scr + o_psc);
+  w.conn_cnt = (int*)(scr + o_ccnt);
+  w.conn_ij = (int*)(scr + o_cij);
+  w.conn_sc = (float*)(scr + o_csc);
+  w.overflow = (int*)(scr + o_ovf);
+  w.scale = scale;
+  w.out_cnt = (int*)(scr + o_ocnt);
+  w.out_kp = (int*)(scr + o_okp);
+  w.out_sc = (double*)(scr + o_osc);
+  TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, 4, ctx->stream));
+  {
+    ta_prof_scope scope(ctx, 3, (double)N * 18 * H8 * W8 * 4);
+    hipLaunchKernelGGL(peaks_kernel, dim3(N * 18), dim3(1024), 0, ctx->stream, w);
+    TA_HIP(ctx, hipGetLastError());
+  }
+  {
+    ta_prof_scope scope(ctx, 3, 0.0);
+    const size_t lds = (size_t)OP_MAXC * 8 + OP_MAXP / 8 + 64;
+    static bool attr = false;
+    if (!attr) {
+      TA_HIP(ctx, hipFuncSetAttribute((const void*)limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(limbs_kernel, dim3(N * 19), dim3(256), lds, ctx->stream, w);
+    TA_HIP(ctx, hipGetLastError());
+  }
+  {
+    ta_prof_scope scope(ctx, 3, 0.0);
+    hipLaunchKernelGGL(assemble_kernel, dim3(N), dim3(64), 0, ctx->stream, w);
+    TA_HIP(ctx, hipGetLastError());
+  }
+  int ovf = 0;
+  TA_HIP(ctx, hipMemcpyAsync(counts, w.out_cnt, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(&ovf, w.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ovf) return ta_fail(ctx, TA_E_OVERFLOW, "openpose: more than %d peaks per part, %d candidate pairs per limb or %d humans in one image", OP_MAXP, OP_MAXC, OP_MAXH);
+  long long total = 0;
+  for (int i = 0; i < N; ++i) total += counts[i];
+  if (required) *required = (int32_t)total;
+  if (total > capacity) return ta_fail(ctx, TA_E_CAPACITY, "openpose: %lld humans, capacity %d", total, capacity);
+  if (total == 0) return TA_OK;
+  hipLaunchKernelGGL(op_gather_kernel, dim3(N), dim3(256), 0, ctx->stream, w, (int*)(scr + o_gkp), (double*)(scr + o_gsc));
+  TA_HIP(ctx, hipGetLastError());
+  TA_HIP(ctx, hipMemcpyAsync(keypoints, scr + o_gkp, (size_t)total * 54 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(scores, scr + o_gsc, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TA_OK;
+}
+
+// host NCHW maps -> device NHWC(c channels) tensor
+static int upload_maps(ta_ctx* ctx, const float* const* srcs, const int* chs, int nsrc, int n, int h, int w, float** dev,
+                       int* ctot) {
+  int c = 0;
+  for (int k = 0; k < nsrc; ++k) c += chs[k];
+  std::vector<float> host((size_t)n * h * w * c);
+  int co = 0;
+  for (int k = 0; k < nsrc; ++k) {
+    for (int i = 0; i < n; ++i)
+      for (int ch = 0; ch < chs[k]; ++ch)
+        for (int y = 0; y < h; ++y)
+          for (int x = 0; x < w; ++x)
+            host[(((size_t)i * h + y) * w + x) * c + co + ch] = srcs[k][(((size_t)i * chs[k] + ch) * h + y) * w + x];
+    co += chs[k];
+  }
+  TA_HIP(ctx, hipMalloc((void**)dev, host.size() * sizeof(float)));
+  hipError_t e = hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(*dev);
+    return ta_fail(ctx, TA_E_DEVICE, "upload failed: %s", hipGetErrorString(e));
+  }
+  *ctot = c;
+  return TA_OK;
+}
+
+extern "C" {
+
+int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capacity, int32_t* counts,
+                    int32_t* keypoints, double* scores, int32_t* required) {
+  if (!m || !frames || !counts) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  if (m->kind != TA_MODEL_OPENPOSE) return ta_fail(ctx, TA_E_INVALID, "openpose_run: wrong model kind");
+  if (capacity > 0 && (!keypoints || !scores)) return ta_fail(ctx, TA_E_INVALID, "openpose_run: null outputs");
+  if (!(scale > 0.0)) return ta_fail(ctx, TA_E_INVALID, "openpose_run: scale must be positive");
+  if (required) *required = 0;
+  if (frames->n == 0) return TA_OK;
+  TA_TRY(ta_model_forward_frames(m, frames));
+  const ta_tensor& X = m->tensors[m->hdr.outputs[0]];
+  op_maps mp;
+  mp.base = X.dev;
+  mp.img = (int)((size_t)X.hp() * X.wp() * X.c);
+  mp.row = X.wp() * X.c;
+  mp.pix = X.c;
+  mp.paf_off = (int)X.off(0, 0, 0) + 128;
+  mp.hm_off = (int)X.off(0, 0, 0) + 168;
+  mp.h = X.h;
+  mp.w = X.w;
+  return op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required, nullptr);
+}
+
+int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w, double scale,
+                      int capacity, int32_t* counts, int32_t* keypoints, double* scores, int32_t* required) {
+  if (!ctx || n < 0 || h <= 0 || w <= 0 || !counts) return TA_E_INVALID;
+  if (required) *required = 0;
+  if (n == 0) return TA_OK;
+  if (!pafs || !heatmaps) return ta_fail(ctx, TA_E_INVALID, "openpose_group: null maps");
+  if (!(scale > 0.0)) return ta_fail(ctx, TA_E_INVALID, "openpose_group: scale must be positive");
+  const float* srcs[2] = {pafs, heatmaps};
+  const int chs[2] = {38, 19};
+  float* dev = nullptr;
+  int c = 0;
+  TA_TRY(upload_maps(ctx, srcs, chs, 2, n, h, w, &dev, &c));
+  op_maps mp;
+  mp.base = dev;
+  mp.img = h * w * c;
+  mp.row = w * c;
+  mp.pix = c;
+  mp.paf_off = 0;
+  mp.hm_off = 38;
+  mp.h = h;
+  mp.w = w;
+  const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required, nullptr);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dev);
+  return rc;
+}
+
+int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out) {
+  if (!ctx || n < 0 || c <= 0 || h <= 0 || w <= 0) return TA_E_INVALID;
+  if (n == 0) return TA_OK;
+  if (!maps || !out) return ta_fail(ctx, TA_E_INVALID, "bicubic: null pointer");
+  // run the 57-channel kernel over channel groups: pad channels to 57 by replicating channel 0
+  for (int c0 = 0; c0 < c; c0 += 57) {
+    const int cc = c - c0 < 57 ? c - c0 : 57;
+    std::vector<float> a((size_t)n * 38 * h * w), b((size_t)n * 19 * h * w);
+    for (int i = 0; i < n; ++i)
+      for (int ch = 0; ch < 57; ++ch) {
+        const int srcc = c0 + (ch < cc ? ch : 0);
+        const float* s = maps + ((size_t)i * c + srcc) * h * w;
+        float* d = ch < 38 ? &a[((size_t)i * 38 + ch) * h * w] : &b[((size_t)i * 19 + (ch - 38)) * h * w];
+        memcpy(d, s, (size_t)h * w * 4);
+      }
+    const float* srcs[2] = {a.data(), b.data()};
+    const int chs[2] = {38, 19};
+    float* dev = nullptr;
+    int ct = 0;
+    TA_TRY(upload_maps(ctx, srcs, chs, 2, n, h, w, &dev, &ct));
+    op_maps mp;
+    mp.base = dev;
+    mp.img = h * w * ct;
+    mp.row = w * ct;
+    mp.pix = ct;
+    mp.paf_off = 0;
+    mp.hm_off = 38;
+    mp.h = h;
+    mp.w = w;
+    std::vector<float> up((size_t)n * 57 * 64 * h * w);
+    const int rc = op_postprocess_dev(ctx, mp, n, 1.0, 0, nullptr, nullptr, nullptr, nullptr, up.data());
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (rc != TA_OK) return rc;
+    for (int i = 0; i < n; ++i)
+      for (int ch = 0; ch < cc; ++ch)
+        memcpy(out + ((size_t)i * c + c0 + ch) * 64 * h * w, &up[((size_t)i * 57 + ch) * 64 * h * w], (size_t)64 * h * w * 4);
+  }
+  return TA_OK;
+}
+
+}  // extern "C"

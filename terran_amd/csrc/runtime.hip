@@ -1,0 +1,355 @@
+// Context, error text, scratch, HIP-event profiling, and device-resident uint8 frame batches
+// (upload, cv2-style bilinear resize, zero-pad paste).
+#include <stdarg.h>
+#include <string.h>
+
+#include "ta_internal.h"
+
+int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int ta_scratch(ta_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    // the old block may still be read by queued kernels: drain first
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    TA_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return TA_OK;
+}
+
+int ta_pinned(ta_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->pinned_bytes) {
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    size_t want = bytes + bytes / 4 + (1 << 16);
+    TA_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+  }
+  *out = ctx->pinned;
+  return TA_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+static hipEvent_t get_event(ta_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+ta_prof_scope::ta_prof_scope(ta_ctx* c, int k, double w) : ctx(c), klass(k), work(w) {
+  if (!ctx->profiling) return;
+  a = get_event(ctx);
+  b = get_event(ctx);
+  if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+ta_prof_scope::~ta_prof_scope() {
+  if (!ctx->profiling || !a || !b) return;
+  (void)hipEventRecord(b, ctx->stream);
+  ctx->pending.push_back({a, b, klass});
+  ctx->prof[klass].launches += 1;
+  ctx->prof[klass].work += work;
+}
+
+static void drain_profile(ta_ctx* ctx) {
+  if (ctx->pending.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& pe : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) ctx->prof[pe.klass].ms += ms;
+    ctx->event_pool.push_back(pe.a);
+    ctx->event_pool.push_back(pe.b);
+  }
+  ctx->pending.clear();
+}
+
+extern "C" {
+
+const char* ta_version(void) { return "terran_amd 0.1.0 (gfx950)"; }
+
+int ta_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ta_ctx_create(int device_id, ta_ctx** out) {
+  if (!out) return TA_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return TA_E_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return TA_E_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return TA_E_DEVICE;   // this library is gfx950-only
+  if (hipSetDevice(device_id) != hipSuccess) return TA_E_DEVICE;
+  ta_ctx* ctx = new ta_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return TA_E_DEVICE;
+  }
+  (void)hipEventCreate(&ctx->t0);
+  (void)hipEventCreate(&ctx->t1);
+  *out = ctx;
+  return TA_OK;
+}
+
+void ta_ctx_destroy(ta_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  drain_profile(ctx);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* ta_last_error(const ta_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ta_ctx_sync(ta_ctx* ctx) {
+  if (!ctx) return TA_E_INVALID;
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TA_OK;
+}
+
+int ta_profile_enable(ta_ctx* ctx, int on) {
+  if (!ctx) return TA_E_INVALID;
+  if (!on) drain_profile(ctx);
+  ctx->profiling = on != 0;
+  return TA_OK;
+}
+
+int ta_profile_reset(ta_ctx* ctx) {
+  if (!ctx) return TA_E_INVALID;
+  drain_profile(ctx);
+  for (auto& p : ctx->prof) p = ta_prof_class();
+  return TA_OK;
+}
+
+int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, double* work) {
+  if (!ctx || klass < 0 || klass > 3) return TA_E_INVALID;
+  drain_profile(ctx);
+  if (ms) *ms = ctx->prof[klass].ms;
+  if (launches) *launches = ctx->prof[klass].launches;
+  if (work) *work = ctx->prof[klass].work;
+  return TA_OK;
+}
+
+int ta_timer_start(ta_ctx* ctx) {
+  if (!ctx) return TA_E_INVALID;
+  TA_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return TA_OK;
+}
+
+int ta_timer_stop(ta_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return TA_E_INVALID;
+  TA_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  TA_HIP(ctx, hipEventSynchronize(ctx->t1));
+  float f = 0.f;
+  TA_HIP(ctx, hipEventElapsedTime(&f, ctx->t0, ctx->t1));
+  *ms = f;
+  return TA_OK;
+}
+
+}  // extern "C"
+
+// ---- frames ------------------------------------------------------------------------------------
+// cv2.resize INTER_LINEAR for uint8 (OpenCV's classic two-pass fixed-point bilinear: 11-bit
+// coefficients; horizontal pass into int, vertical pass ((b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2)>>2).
+// Coefficient tables are built on the host exactly as oracle/facade.py does and uploaded.
+__global__ __launch_bounds__(256) void resize_linear_kernel(const uint8_t* src, int N, int H, int W, uint8_t* dst,
+                                                             int dh, int dw, const int32_t* xtab, const int32_t* ytab) {
+  // xtab: [dw][4] = sx0, sx1, a0, a1 ; ytab: [dh][4] = y0, y1, b0, b1
+  const size_t total = (size_t)N * dh * dw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t pix = i;
+    const int x = (int)(pix % dw);
+    pix /= dw;
+    const int y = (int)(pix % dh);
+    const int img = (int)(pix / dh);
+    const int4 xt = *(const int4*)(xtab + 4 * x);
+    const int4 yt = *(const int4*)(ytab + 4 * y);
+    const uint8_t* r0 = src + ((size_t)img * H + yt.x) * W * 3;
+    const uint8_t* r1 = src + ((size_t)img * H + yt.y) * W * 3;
+    uint8_t o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h0 = r0[xt.x * 3 + c] * xt.z + r0[xt.y * 3 + c] * xt.w;
+      const int h1 = r1[xt.x * 3 + c] * xt.z + r1[xt.y * 3 + c] * xt.w;
+      int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      o[c] = (uint8_t)v;
+    }
+    uint8_t* d = dst + i * 3;
+    d[0] = o[0];
+    d[1] = o[1];
+    d[2] = o[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void paste_kernel(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw,
+                                                     int top, int left) {
+  const size_t total = (size_t)sh * sw * 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    size_t pix = i / 3;
+    const int x = (int)(pix % sw);
+    const int y = (int)(pix / sw);
+    dst[((size_t)(y + top) * dw + x + left) * 3 + c] = src[i];
+  }
+}
+
+#include <cmath>
+static void axis_table(int src, int dst, bool clamp_frac, std::vector<int32_t>& tab) {
+  // mirrors oracle/facade.py:_axis_coeffs/_to_short (OpenCV resize.cpp semantics)
+  tab.resize((size_t)dst * 4);
+  const double scale = 1.0 / ((double)dst / (double)src);
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f = f - (float)s;
+    int s0, s1;
+    if (clamp_frac) {
+      if (s < 0) { f = 0.f; s = 0; }
+      if (s >= src - 1) { f = 0.f; s = src - 1; }
+      s0 = s;
+      s1 = s + 1 < src ? s + 1 : src - 1;
+    } else {
+      s0 = s < 0 ? 0 : (s > src - 1 ? src - 1 : s);
+      s1 = s + 1 < 0 ? 0 : (s + 1 > src - 1 ? src - 1 : s + 1);
+    }
+    auto to_short = [](float c) {
+      float v = nearbyintf(c * 2048.0f);   // round half to even (default rounding mode)
+      if (v > 32767.f) v = 32767.f;
+      if (v < -32768.f) v = -32768.f;
+      return (int32_t)v;
+    };
+    tab[4 * d + 0] = s0;
+    tab[4 * d + 1] = s1;
+    tab[4 * d + 2] = to_short(1.0f - f);
+    tab[4 * d + 3] = to_short(f);
+  }
+}
+
+extern "C" {
+
+int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
+  if (!ctx || !out || n < 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_alloc: bad shape");
+  ta_frames* f = new ta_frames{ctx, n, h, w, nullptr};
+  size_t bytes = (size_t)n * h * w * 3;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc((void**)&f->dev, bytes);
+  if (e != hipSuccess) {
+    delete f;
+    return ta_fail(ctx, TA_E_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  TA_HIP(ctx, hipMemsetAsync(f->dev, 0, bytes, ctx->stream));
+  *out = f;
+  return TA_OK;
+}
+
+int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, ta_frames** out) {
+  if (!nhwc_rgb && n > 0) return ta_fail(ctx, TA_E_INVALID, "frames_upload: null data");
+  TA_TRY(ta_frames_alloc(ctx, n, h, w, out));
+  const size_t bytes = (size_t)n * h * w * 3;
+  if (bytes) {
+    TA_HIP(ctx, hipMemcpyAsync((*out)->dev, nhwc_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller's buffer may be reused immediately
+  }
+  return TA_OK;
+}
+
+int ta_frames_shape(const ta_frames* f, int* n, int* h, int* w) {
+  if (!f) return TA_E_INVALID;
+  if (n) *n = f->n;
+  if (h) *h = f->h;
+  if (w) *w = f->w;
+  return TA_OK;
+}
+
+int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb) {
+  if (!f || !nhwc_rgb) return TA_E_INVALID;
+  ta_ctx* ctx = f->ctx;
+  const size_t bytes = (size_t)f->n * f->h * f->w * 3;
+  if (bytes) {
+    TA_HIP(ctx, hipMemcpyAsync(nhwc_rgb, f->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TA_OK;
+}
+
+void ta_frames_free(ta_frames* f) {
+  if (!f) return;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->dev) (void)hipFree(f->dev);
+  delete f;
+}
+
+int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out) {
+  if (!ctx || !src || !out || dst_h <= 0 || dst_w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_resize: bad args");
+  TA_TRY(ta_frames_alloc(ctx, src->n, dst_h, dst_w, out));
+  std::vector<int32_t> xt, yt;
+  axis_table(src->w, dst_w, true, xt);
+  axis_table(src->h, dst_h, false, yt);
+  void* scr = nullptr;
+  const size_t tb = (xt.size() + yt.size()) * sizeof(int32_t);
+  TA_TRY(ta_scratch(ctx, tb, &scr));
+  void* pin = nullptr;
+  TA_TRY(ta_pinned(ctx, tb, &pin));
+  memcpy(pin, xt.data(), xt.size() * 4);
+  memcpy((char*)pin + xt.size() * 4, yt.data(), yt.size() * 4);
+  TA_HIP(ctx, hipMemcpyAsync(scr, pin, tb, hipMemcpyHostToDevice, ctx->stream));
+  const size_t total = (size_t)src->n * dst_h * dst_w;
+  if (total) {
+    ta_prof_scope scope(ctx, 2, (double)total * 3 * 5);
+    size_t g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((int)g), dim3(256), 0, ctx->stream, src->dev, src->n, src->h, src->w,
+                       (*out)->dev, dst_h, dst_w, (const int32_t*)scr, (const int32_t*)scr + xt.size());
+    TA_HIP(ctx, hipGetLastError());
+  }
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // pinned/scratch tables are reused by later calls
+  return TA_OK;
+}
+
+int ta_frames_paste(ta_ctx* ctx, const ta_frames* src, int src_index, ta_frames* dst, int dst_index, int top, int left) {
+  if (!ctx || !src || !dst || src_index < 0 || src_index >= src->n || dst_index < 0 || dst_index >= dst->n ||
+      top < 0 || left < 0 || top + src->h > dst->h || left + src->w > dst->w)
+    return ta_fail(ctx, TA_E_INVALID, "frames_paste: bad args");
+  const size_t total = (size_t)src->h * src->w * 3;
+  size_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(paste_kernel, dim3((int)g), dim3(256), 0, ctx->stream,
+                     src->dev + (size_t)src_index * src->h * src->w * 3, src->h, src->w,
+                     dst->dev + (size_t)dst_index * dst->h * dst->w * 3, dst->h, dst->w, top, left);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+}  // extern "C"

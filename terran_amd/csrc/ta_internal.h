@@ -1,0 +1,192 @@
+// Internal declarations shared by the translation units of libterran_amd.so.
+// gfx950 only: no CUDA/other-arch paths anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/terran_amd.h"
+
+// ---------------------------------------------------------------------------------------------
+// Packed model blob (written by terran_amd/pack.py, parsed by net.cpp).  All little-endian PODs.
+// ---------------------------------------------------------------------------------------------
+#define TA_BLOB_MAGIC 0x314D4154u /* "TAM1" */
+
+enum { TA_OP_CONV = 1, TA_OP_DWCONV = 2, TA_OP_MAXPOOL = 3, TA_OP_COPYCH = 4 };
+enum { TA_ACT_NONE = 0, TA_ACT_RELU = 1, TA_ACT_PRELU = 2 };
+
+struct ta_blob_header {
+  uint32_t magic;
+  uint32_t version;
+  int32_t kind;        // TA_MODEL_*
+  int32_t n_tensors;
+  int32_t n_ops;
+  int32_t input_tensor;   // tensor id the pre-processing kernel fills
+  int32_t n_outputs;      // named outputs (ids in `outputs`)
+  int32_t outputs[16];
+  int64_t tensors_off, ops_off, weights_off, weights_bytes;
+};
+
+// Activation tensor: NHWC float32 with a physical zero halo of `halo` pixels on every side.
+struct ta_tensor_desc {
+  int32_t channels;   // C_total (multiple of 4)
+  int32_t halo;
+  int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0)
+  int32_t reserved;
+};
+
+struct ta_op_desc {
+  int32_t type;
+  int32_t in, out;             // tensor ids
+  int32_t in_ch_off, cin;      // input channel slice; cin multiple of 4
+  int32_t out_ch_off, cout;    // output channel slice; cout multiple of 4
+  int32_t coutp;               // cout padded to a multiple of 32 (packed weight rows)
+  int32_t kh, kw, stride, pad;
+  int32_t act;
+  int32_t res, res_ch_off, res_up2;   // residual tensor (-1 none); res_up2: read residual at (y/2, x/2)
+  int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
+  int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
+  int32_t reserved;
+  int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
+  double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
+};
+
+// ---------------------------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------------------------
+struct ta_prof_class {
+  double ms = 0;
+  int64_t launches = 0;
+  double work = 0;
+};
+
+struct ta_pending_event {
+  hipEvent_t a, b;
+  int klass;
+};
+
+struct ta_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  ta_prof_class prof[4];
+  std::vector<ta_pending_event> pending;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // grow-only device scratch + pinned host staging
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...);
+int ta_scratch(ta_ctx* ctx, size_t bytes, void** out);   // device scratch, valid until next call
+int ta_pinned(ta_ctx* ctx, size_t bytes, void** out);    // pinned host staging
+
+#define TA_HIP(ctx, expr)                                                                      \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return ta_fail((ctx), TA_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                      \
+  } while (0)
+
+#define TA_TRY(expr)            \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != TA_OK) return _r; \
+  } while (0)
+
+// profiling scope: records an event pair around a launch when ctx->profiling
+struct ta_prof_scope {
+  ta_ctx* ctx;
+  int klass;
+  double work;
+  hipEvent_t a = nullptr, b = nullptr;
+  ta_prof_scope(ta_ctx* c, int k, double w);
+  ~ta_prof_scope();
+};
+
+struct ta_frames {
+  ta_ctx* ctx;
+  int n, h, w;
+  uint8_t* dev;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Planned tensors / kernels
+// ---------------------------------------------------------------------------------------------
+struct ta_tensor {
+  float* dev = nullptr;   // base of the padded allocation
+  int n = 0, h = 0, w = 0, c = 0, halo = 0;
+  bool owns = true;
+  int hp() const { return h + 2 * halo; }
+  int wp() const { return w + 2 * halo; }
+  size_t elems() const { return (size_t)n * hp() * wp() * c; }
+  // element offset of interior pixel (img, y, x), channel 0
+  size_t off(int img, int y, int x) const { return (((size_t)img * hp() + y + halo) * wp() + x + halo) * c; }
+};
+
+struct ta_conv_launch {
+  const float* in;
+  const float* w;
+  const int32_t* ktab;
+  const float* bias;
+  const float* prelu;
+  float* out;
+  const float* res;
+  float* out2;
+  const float* scale2;
+  const float* shift2;
+  int M, Ho, Wo, n_slabs, coutp, cout, act, stride;
+  // element strides / offsets
+  int in_img, in_row, in_pix, in_off0;
+  int out_img, out_row, out_pix, out_off0;
+  int res_img, res_row, res_pix, res_off0, res_up2;
+  int o2_img, o2_row, o2_pix, o2_off0;
+};
+
+int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);
+
+struct ta_dw_launch {
+  const float* in;
+  const float* w;      // [9][C]
+  const float* bias;   // [C]
+  float* out;
+  int N, Ho, Wo, C, stride, relu;
+  int in_img, in_row, in_pix, in_off0;
+  int out_img, out_row, out_pix, out_off0;
+};
+int ta_launch_dwconv(ta_ctx* ctx, const ta_dw_launch& p);
+int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out);
+int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch);
+
+// pre-processing: uint8 frames -> float NHWC(4) with halo
+enum { TA_PRE_RETINAFACE = 1, TA_PRE_OPENPOSE = 2, TA_PRE_ARCFACE_CROPS = 3 };
+int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, int h, int w, const ta_tensor& dst);
+
+// ---------------------------------------------------------------------------------------------
+// Model
+// ---------------------------------------------------------------------------------------------
+struct ta_model {
+  ta_ctx* ctx = nullptr;
+  int kind = 0;
+  ta_blob_header hdr;
+  std::vector<ta_tensor_desc> tdesc;
+  std::vector<ta_op_desc> ops;
+  char* weights_dev = nullptr;
+  // current plan
+  int plan_n = 0, plan_h = 0, plan_w = 0;
+  std::vector<ta_tensor> tensors;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int32_t* ktab_dev = nullptr;
+  std::vector<size_t> ktab_off;   // per op, element offset into ktab_dev
+};
+
+int ta_model_plan(ta_model* m, int n, int h, int w);
+int ta_model_run_ops(ta_model* m);

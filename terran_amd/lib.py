@@ -1,0 +1,255 @@
+"""ctypes binding of `libterran_amd.so` (the C ABI in include/terran_amd.h).
+
+There is no fallback: if the library is missing or no gfx950 device is usable, the
+product path raises `TerranAmdError`.  Nothing here imports `oracle/`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libterran_amd.so')
+
+OK, E_INVALID, E_DEVICE, E_CAPACITY, E_OVERFLOW = 0, -1, -2, -3, -4
+_CODES = {E_INVALID: 'TA_E_INVALID', E_DEVICE: 'TA_E_DEVICE', E_CAPACITY: 'TA_E_CAPACITY', E_OVERFLOW: 'TA_E_OVERFLOW'}
+
+
+class TerranAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('%s: %s' % (_CODES.get(code, code), msg))
+        self.code = code
+
+
+c_int, c_float, c_double, c_void_p, c_size_t = C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+P = C.POINTER
+u8p, i32p, f32p, f64p = P(C.c_uint8), P(C.c_int32), P(C.c_float), P(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/terran_amd.h one to one
+SIGNATURES = {
+    'ta_version': (C.c_char_p, []),
+    'ta_device_count': (c_int, []),
+    'ta_ctx_create': (c_int, [c_int, P(c_void_p)]),
+    'ta_ctx_destroy': (None, [c_void_p]),
+    'ta_last_error': (C.c_char_p, [c_void_p]),
+    'ta_ctx_sync': (c_int, [c_void_p]),
+    'ta_profile_enable': (c_int, [c_void_p, c_int]),
+    'ta_profile_reset': (c_int, [c_void_p]),
+    'ta_profile_read': (c_int, [c_void_p, c_int, f64p, P(C.c_int64), f64p]),
+    'ta_timer_start': (c_int, [c_void_p]),
+    'ta_timer_stop': (c_int, [c_void_p, f64p]),
+    'ta_frames_upload': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, P(c_void_p)]),
+    'ta_frames_alloc': (c_int, [c_void_p, c_int, c_int, c_int, P(c_void_p)]),
+    'ta_frames_shape': (c_int, [c_void_p, P(c_int), P(c_int), P(c_int)]),
+    'ta_frames_download': (c_int, [c_void_p, c_void_p]),
+    'ta_frames_free': (None, [c_void_p]),
+    'ta_frames_resize': (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_void_p)]),
+    'ta_frames_paste': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
+    'ta_model_load': (c_int, [c_void_p, c_int, c_void_p, c_size_t, P(c_void_p)]),
+    'ta_model_free': (None, [c_void_p]),
+    'ta_model_kind': (c_int, [c_void_p]),
+    'ta_model_forward_frames': (c_int, [c_void_p, c_void_p]),
+    'ta_model_forward_crops': (c_int, [c_void_p, c_void_p, c_int]),
+    'ta_model_tensor_shape': (c_int, [c_void_p, c_int, P(c_int), P(c_int), P(c_int), P(c_int)]),
+    'ta_model_read_tensor': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ta_retinaface_run': (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, P(C.c_int32)]),
+    'ta_retinaface_postprocess': (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_float, c_float, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, P(C.c_int32)]),
+    'ta_arcface_embed_crops': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'ta_arcface_embed_faces': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'ta_cosine_distance': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'ta_openpose_run': (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, P(C.c_int32)]),
+    'ta_openpose_group': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p,
+                                  c_void_p, c_void_p, P(C.c_int32)]),
+    'ta_bicubic_x8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TerranAmdError(E_DEVICE, 'libterran_amd.so not built (run `python -m terran_amd.build`); '
+                                           'there is no CPU fallback')
+        lib = C.CDLL(LIB_PATH)
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        if missing and not os.environ.get('TA_BRINGUP_ALLOW_MISSING'):
+            raise TerranAmdError(E_INVALID, 'libterran_amd.so lacks ABI symbols: %s' % ', '.join(missing))
+        _lib = lib
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_void_p) if a is not None else None
+
+
+class Context:
+    """One per GPU (and per host thread)."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        h = c_void_p()
+        rc = self.lib.ta_ctx_create(int(device_id), C.byref(h))
+        if rc != OK:
+            raise TerranAmdError(rc, 'ta_ctx_create(%d) failed: no usable gfx950 device '
+                                     '(ta_device_count=%d)' % (device_id, self.lib.ta_device_count()))
+        self.h = h
+        self.device_id = device_id
+
+    def check(self, rc):
+        if rc != OK:
+            raise TerranAmdError(rc, self.lib.ta_last_error(self.h).decode(errors='replace'))
+
+    def sync(self):
+        self.check(self.lib.ta_ctx_sync(self.h))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.ta_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # profiling / timing
+    def profile(self, on):
+        self.check(self.lib.ta_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(self.lib.ta_profile_reset(self.h))
+
+    def profile_read(self, klass):
+        ms, n, w = c_double(), C.c_int64(), c_double()
+        self.check(self.lib.ta_profile_read(self.h, klass, C.byref(ms), C.byref(n), C.byref(w)))
+        return ms.value, n.value, w.value
+
+    def timer_start(self):
+        self.check(self.lib.ta_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = c_double()
+        self.check(self.lib.ta_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # frames
+    def upload(self, images):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        assert images.ndim == 4 and images.shape[3] == 3
+        return Frames(self, images)
+
+    def cosine_distance(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self.check(self.lib.ta_cosine_distance(self.h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1], ptr(out)))
+        return out
+
+    def bicubic_x8(self, maps):
+        maps = np.ascontiguousarray(maps, dtype=np.float32)
+        n, c, h, w = maps.shape
+        out = np.empty((n, c, 8 * h, 8 * w), np.float32)
+        self.check(self.lib.ta_bicubic_x8(self.h, ptr(maps), n, c, h, w, ptr(out)))
+        return out
+
+
+class Frames:
+    """uint8 RGB (N,H,W,3) batch resident in HBM."""
+
+    def __init__(self, ctx, images=None, handle=None):
+        self.ctx = ctx
+        if handle is not None:
+            self.h = handle
+        else:
+            h = c_void_p()
+            n, hh, ww = images.shape[:3]
+            ctx.check(ctx.lib.ta_frames_upload(ctx.h, ptr(images), n, hh, ww, C.byref(h)))
+            self.h = h
+        n, hh, ww = c_int(), c_int(), c_int()
+        ctx.lib.ta_frames_shape(self.h, C.byref(n), C.byref(hh), C.byref(ww))
+        self.shape = (n.value, hh.value, ww.value, 3)
+
+    @classmethod
+    def zeros(cls, ctx, n, h, w):
+        hd = c_void_p()
+        ctx.check(ctx.lib.ta_frames_alloc(ctx.h, n, h, w, C.byref(hd)))
+        return cls(ctx, handle=hd)
+
+    def resize(self, h, w):
+        hd = c_void_p()
+        self.ctx.check(self.ctx.lib.ta_frames_resize(self.ctx.h, self.h, int(h), int(w), C.byref(hd)))
+        return Frames(self.ctx, handle=hd)
+
+    def paste(self, src, src_index, dst_index, top, left):
+        self.ctx.check(self.ctx.lib.ta_frames_paste(self.ctx.h, src.h, src_index, self.h, dst_index, top, left))
+
+    def download(self):
+        out = np.empty(self.shape, np.uint8)
+        self.ctx.check(self.ctx.lib.ta_frames_download(self.h, ptr(out)))
+        return out
+
+    def free(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.ta_frames_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Model:
+    """A packed model on one context."""
+
+    def __init__(self, ctx, program):
+        self.ctx = ctx
+        self.kind = program.kind
+        self.names = dict(program.names)
+        blob = program.blob()
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        h = c_void_p()
+        ctx.check(ctx.lib.ta_model_load(ctx.h, program.kind, ptr(buf), len(blob), C.byref(h)))
+        self.h = h
+
+    def forward_frames(self, frames):
+        self.ctx.check(self.ctx.lib.ta_model_forward_frames(self.h, frames.h))
+
+    def forward_crops(self, crops):
+        crops = np.ascontiguousarray(crops, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ta_model_forward_crops(self.h, ptr(crops), crops.shape[0]))
+
+    def read(self, name):
+        """Debug tap: named tensor slice as float32 NCHW."""
+        tid, off, ch = self.names[name]
+        n, c, h, w = c_int(), c_int(), c_int(), c_int()
+        self.ctx.check(self.ctx.lib.ta_model_tensor_shape(self.h, tid, C.byref(n), C.byref(c), C.byref(h), C.byref(w)))
+        out = np.empty((n.value, ch, h.value, w.value), np.float32)
+        self.ctx.check(self.ctx.lib.ta_model_read_tensor(self.h, tid, off, ch, ptr(out)))
+        return out
+
+    def free(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.ta_model_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,393 @@
+"""Pack a Terran `state_dict` into the op program + weight blob `libterran_amd.so` runs.
+
+Replaces the reference's `load_model()` + `nn.Module` construction
+(retinaface/wrapper.py:16-22, arcface/wrapper.py:13-19, openpose/wrapper.py:27-36):
+BatchNorms are folded (float64 math, float32 result), weights are laid out for the
+implicit-GEMM kernel ([K-slab][cout][32 floats], K = (ky,kx,cin) with cin fastest), and
+the graph is flattened into conv / depthwise / pool / copy ops over halo-padded NHWC
+tensors.  Concats become channel slices of a shared tensor; the few graph-level fusions
+(merged sibling convs, residual/upsample-add and the next unit's BatchNorm in the conv
+epilogue) are documented next to each builder.
+
+Blob layout mirrors `terran_amd/csrc/ta_internal.h` (ta_blob_header / ta_tensor_desc /
+ta_op_desc).
+"""
+import numpy as np
+
+from . import arch
+
+MODEL_RETINAFACE, MODEL_ARCFACE, MODEL_OPENPOSE = 1, 2, 3
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_COPYCH = 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+MAGIC = 0x314D4154
+
+HEADER_DT = np.dtype({
+    'names': ['magic', 'version', 'kind', 'n_tensors', 'n_ops', 'input_tensor', 'n_outputs', 'outputs',
+              'tensors_off', 'ops_off', 'weights_off', 'weights_bytes'],
+    'formats': ['<u4', '<u4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', 16), '<i8', '<i8', '<i8', '<i8'],
+    'offsets': [0, 4, 8, 12, 16, 20, 24, 28, 96, 104, 112, 120],
+    'itemsize': 128,
+})
+TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('reserved', '<i4')])
+_OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'reserved']
+_OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
+OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
+assert OP_DT.itemsize == 128 and TENSOR_DT.itemsize == 16
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Program:
+    """Accumulates tensors, ops and the weight region of one model."""
+
+    def __init__(self, kind):
+        self.kind = kind
+        self.tensors = []      # (channels, halo, alias_of)
+        self.ops = []
+        self.wchunks = []
+        self.wbytes = 0
+        self.names = {}        # debug taps: name -> (tensor, ch_off, ch)
+        self.input_tensor = None
+        self.outputs = []
+
+    def tensor(self, channels, halo, alias_of=-1, name=None):
+        assert channels % 4 == 0
+        self.tensors.append((channels, halo, alias_of))
+        tid = len(self.tensors) - 1
+        if name:
+            self.names[name] = (tid, 0, channels)
+        return tid
+
+    def tap(self, name, tid, ch_off, ch):
+        self.names[name] = (tid, ch_off, ch)
+
+    def _w(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        off = self.wbytes
+        self.wchunks.append(arr.tobytes())
+        pad = (-len(self.wchunks[-1])) % 256
+        if pad:
+            self.wchunks.append(b'\0' * pad)
+        self.wbytes += arr.nbytes + pad
+        return off
+
+    def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
+             out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
+             scale2=None, shift2=None):
+        """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
+        ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p)."""
+        W = np.asarray(W, dtype=np.float64)
+        cout, cin, kh, kw = W.shape
+        if pad is None:
+            pad = kh // 2
+        if cin_p is None:
+            cin_p = _rup(cin, 4)
+        if ch_pos is None:
+            ch_pos = np.arange(cin)
+        if cout_p is None:
+            cout_p = _rup(cout, 4)
+        coutp = _rup(cout_p, 32)
+        K = kh * kw * cin_p
+        n_slabs = _rup(K, 32) // 32
+        full = np.zeros((kh * kw, cin_p, coutp), np.float32)
+        full[:, np.asarray(ch_pos), :cout] = W.transpose(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+        flat = np.zeros((n_slabs * 32, coutp), np.float32)
+        flat[:K] = full.reshape(K, coutp)
+        packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
+
+        def vec(v):
+            if v is None:
+                return -1
+            out = np.zeros(coutp, np.float32)
+            out[:cout] = np.asarray(v, dtype=np.float64)
+            return self._w(out)
+        op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
+                  coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
+                  res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, reserved=0,
+                  w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
+        op['in'] = tin
+        self.ops.append(op)
+
+    def dwconv(self, tin, tout, W, bias, *, stride=1, relu=True):
+        """W: (C,1,3,3) folded, bias (C,)."""
+        C = W.shape[0]
+        w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
+        op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
+                  kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
+                  out2=-1, out2_ch_off=0, n_slabs=0, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
+        op['in'] = tin
+        self.ops.append(op)
+
+    def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
+        op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
+                  kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
+                  reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=0.0)
+        op['in'] = tin
+        self.ops.append(op)
+
+    def blob(self):
+        hdr = np.zeros(1, HEADER_DT)
+        tens = np.zeros(len(self.tensors), TENSOR_DT)
+        for i, (c, h, a) in enumerate(self.tensors):
+            tens[i] = (c, h, a, 0)
+        ops = np.zeros(len(self.ops), OP_DT)
+        for i, op in enumerate(self.ops):
+            for k, v in op.items():
+                ops[i][k] = v
+        t_off = HEADER_DT.itemsize
+        o_off = t_off + tens.nbytes
+        w_off = _rup(o_off + ops.nbytes, 256)
+        outs = np.full(16, -1, np.int32)
+        outs[:len(self.outputs)] = self.outputs
+        hdr[0] = (MAGIC, 1, self.kind, len(self.tensors), len(self.ops), self.input_tensor, len(self.outputs), outs,
+                  t_off, o_off, w_off, self.wbytes)
+        head = hdr.tobytes() + tens.tobytes() + ops.tobytes()
+        return head + b'\0' * (w_off - len(head)) + b''.join(self.wchunks)
+
+
+# ---- BatchNorm folding -------------------------------------------------------------------
+def _bn_affine(sd, key, eps):
+    g = np.asarray(sd[key + '.weight'], np.float64)
+    b = np.asarray(sd[key + '.bias'], np.float64)
+    m = np.asarray(sd[key + '.running_mean'], np.float64)
+    v = np.asarray(sd[key + '.running_var'], np.float64)
+    s = g / np.sqrt(v + eps)
+    return s, b - m * s
+
+
+def _fold(W, bias, scale, shift):
+    """BN(conv(x)+bias) -> conv'(x)+bias'."""
+    W = np.asarray(W, np.float64) * scale[:, None, None, None]
+    b0 = np.zeros(W.shape[0]) if bias is None else np.asarray(bias, np.float64)
+    return W, b0 * scale + shift
+
+
+# ---- OpenPose ------------------------------------------------------------------------------
+# Concat tensor channel layout (192): feat 0..127 | PAF 128..165 (+2 zero) | HM 168..186 (+5 zero).
+OP_FEAT, OP_PAF, OP_HM, OP_XCH = 0, 128, 168, 192
+
+
+def pack_openpose(sd):
+    """openpose/model.py:27-141.  Stage inputs cat[PAF, HM, feat] live in two ping-pong
+    192-channel tensors; every stage-output conv writes its slice directly."""
+    P = Program(MODEL_OPENPOSE)
+    t = P.tensor(4, 1, name='input')
+    P.input_tensor = t
+    X0 = P.tensor(OP_XCH, 3, name='X0')
+    X1 = P.tensor(OP_XCH, 3, name='X1')
+    items = arch.OPENPOSE_MODEL0
+    for i, item in enumerate(items):
+        nxt = items[i + 1] if i + 1 < len(items) else None
+        if item[0] == 'pool':
+            o = P.tensor(P.tensors[t][0], 1)
+            P.simple(OP_MAXPOOL, t, o)
+            t = o
+            continue
+        name, cin, cout, k = item
+        W, b = sd['model0.%s.weight' % name], sd['model0.%s.bias' % name]
+        if nxt is None:       # conv4_4_CPM -> feature slice of X0
+            P.conv(t, X0, W, b, act=ACT_RELU, out_ch_off=OP_FEAT)
+            P.tap('feat', X0, OP_FEAT, 128)
+        else:
+            o = P.tensor(cout, 0 if nxt[0] == 'pool' else 1, name=name)
+            P.conv(t, o, W, b, act=ACT_RELU)
+            t = o
+    P.simple(OP_COPYCH, X0, X1, OP_FEAT, OP_FEAT, 128)
+
+    # true input channel (cat order PAF38, HM19, feat128) -> position in the 192-channel tensor
+    cat_pos = np.concatenate([OP_PAF + np.arange(38), OP_HM + np.arange(19), OP_FEAT + np.arange(128)])
+    for st in range(1, 7):
+        xin, xout = (X0, X1) if st % 2 == 1 else (X1, X0)
+        for br in (1, 2):
+            layers = arch.openpose_stage_layers(st, br)
+            cur = xin
+            for li, (name, cin, cout, k, relu) in enumerate(layers):
+                key = 'model%d_%d.%s' % (st, br, name)
+                W, b = sd[key + '.weight'], sd[key + '.bias']
+                act = ACT_RELU if relu else ACT_NONE
+                last = li == len(layers) - 1
+                kw = {}
+                if cur == xin:
+                    if cin == 185:
+                        kw = dict(ch_pos=cat_pos, cin_p=OP_XCH)
+                    else:                       # stage 1 reads only the feature slice
+                        kw = dict(in_ch_off=OP_FEAT)
+                if last:
+                    off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
+                    P.conv(cur, xout, W, b, act=act, out_ch_off=off, cout_p=cp, **kw)
+                    P.tap('stage%d_%s' % (st, 'paf' if br == 1 else 'hm'), xout, off, cout)
+                else:
+                    nk = layers[li + 1][3]
+                    o = P.tensor(cout, nk // 2)
+                    P.conv(cur, o, W, b, act=act, **kw)
+                    cur = o
+    P.outputs = [X0]
+    P.tap('pafs', X0, OP_PAF, 38)
+    P.tap('heatmaps', X0, OP_HM, 19)
+    return P
+
+
+# ---- ArcFace -------------------------------------------------------------------------------
+def pack_arcface(sd):
+    """arcface/model.py:4-97.  The residual stream R is kept raw (halo 0); each conv that
+    closes a unit also emits Z = BN_next(R) (halo 1) for the next unit's first conv, so the
+    pre-conv BatchNorm (model.py:12) is applied before zero padding exactly as the reference does."""
+    eps = arch.ARC_BN_EPS
+    P = Program(MODEL_ARCFACE)
+    tin = P.tensor(4, 1, name='input')
+    P.input_tensor = tin
+    units = list(arch.arcface_units())
+
+    def next_bn(i):
+        if i < len(units):
+            st, u = units[i][0], units[i][1]
+            return _bn_affine(sd, 'stages.%d.%d.body.0' % (st, u), eps)
+        return _bn_affine(sd, 'final_layer.0', eps)
+
+    s, sh = _bn_affine(sd, 'initial_layer.1', eps)
+    W, b = _fold(sd['initial_layer.0.weight'], None, s, sh)
+    R = P.tensor(64, 0, name='stem')
+    s2, sh2 = next_bn(0)
+    Z = P.tensor(64, 1)
+    P.conv(tin, R, W, b, act=ACT_PRELU, prelu=sd['initial_layer.2.weight'], out2=Z, scale2=s2, shift2=sh2)
+    for i, (st, u, cin, cout, stride, sc) in enumerate(units):
+        p = 'stages.%d.%d' % (st, u)
+        s, sh = _bn_affine(sd, p + '.body.2', eps)
+        W1, b1 = _fold(sd[p + '.body.1.weight'], None, s, sh)
+        Y = P.tensor(cout, 1)
+        P.conv(Z, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'])
+        if sc:
+            s, sh = _bn_affine(sd, p + '.shortcut.1', eps)
+            Ws, bs = _fold(sd[p + '.shortcut.0.weight'], None, s, sh)
+            S = P.tensor(cout, 0)
+            P.conv(R, S, Ws, bs, stride=stride, pad=0)
+            res = S
+        else:
+            res = R
+        s, sh = _bn_affine(sd, p + '.body.5', eps)
+        W2, b2 = _fold(sd[p + '.body.4.weight'], None, s, sh)
+        last = i == len(units) - 1
+        Rn = P.tensor(cout, 0)
+        Zn = P.tensor(cout, 0 if last else 1)
+        s2, sh2 = next_bn(i + 1)
+        P.conv(Y, Rn, W2, b2, stride=stride, res=res, out2=Zn, scale2=s2, shift2=sh2)
+        if u == arch.ARC_UNITS[st] - 1:
+            P.tap('stage%d' % (st + 1), Rn, 0, cout)
+        R, Z = Rn, Zn
+    # head: Flatten(C,H,W) -> Linear -> BN1d, as a 1x1 conv over the (N,1,1,25088) NHWC view of Z
+    A = P.tensor(7 * 7 * 512, 0, alias_of=Z)
+    s, sh = _bn_affine(sd, 'final_layer.4', eps)
+    Wl = np.asarray(sd['final_layer.3.weight'], np.float64) * s[:, None]
+    bl = np.asarray(sd['final_layer.3.bias'], np.float64) * s + sh
+    f = np.arange(7 * 7 * 512)
+    ch_pos = (f % 49) * 512 + f // 49
+    E = P.tensor(512, 0, name='embedding')
+    P.conv(A, E, Wl.reshape(512, 7 * 7 * 512, 1, 1), bl, ch_pos=ch_pos, pad=0)
+    P.outputs = [E]
+    return P
+
+
+# ---- RetinaFace ----------------------------------------------------------------------------
+# Context tensor channel layout (96): ctx3x3 0..31 | reducer 32..47 | ctx5x5 48..63 | 7x7-mid 64..79 |
+# ctx7x7 80..95; the merged head conv reads all 96 with zero weights on reducer / 7x7-mid.
+def pack_retinaface(sd):
+    """retinaface/model.py:53-316.  Sibling convs that share an input are merged (ctx3x3+reducer,
+    ctx5x5+ctx7x7.0, cls+bbox+landmark heads); the FPN nearest-x2 upsample + add is the
+    residual of the lateral 1x1 conv's epilogue."""
+    P = Program(MODEL_RETINAFACE)
+    tin = P.tensor(4, 1, name='input')
+    P.input_tensor = tin
+    eps = arch.RETINA_BASE_BN_EPS
+
+    def cbr(key_conv, key_bn, e=eps, bias=False):
+        s, sh = _bn_affine(sd, key_bn, e)
+        return _fold(sd[key_conv + '.weight'], sd[key_conv + '.bias'] if bias else None, s, sh)
+
+    W, b = cbr('base.first_conv_block.0', 'base.first_conv_block.1')
+    a0 = P.tensor(8, 1)
+    P.conv(tin, a0, W, b, stride=2, act=ACT_RELU)
+    W, b = cbr('base.first_conv_block.3', 'base.first_conv_block.4')
+    t = P.tensor(8, 0, name='stem')
+    P.dwconv(a0, t, W, b)
+    feats = []
+    for si, scale in enumerate(arch.RETINA_SCALES):
+        for bi, (cin, cout, stride, both) in enumerate(scale):
+            p = 'base.scales.%d.%d' % (si, bi)
+            W, b = cbr(p + '.conv_block.0', p + '.conv_block.1')
+            c = P.tensor(cout, 1)
+            P.conv(t, c, W, b, act=ACT_RELU)
+            W, b = cbr(p + '.sep_block.0', p + '.sep_block.1')
+            t = P.tensor(cout, 0)
+            P.dwconv(c, t, W, b, stride=stride)
+            if both:
+                feats.append(c)
+    p = 'base.final_conv.0'
+    W, b = cbr(p + '.conv_block.0', p + '.conv_block.1')
+    c = P.tensor(256, 1)
+    P.conv(t, c, W, b, act=ACT_RELU)
+    W, b = cbr(p + '.sep_block.0', p + '.sep_block.1')
+    t = P.tensor(256, 0)
+    P.dwconv(c, t, W, b)
+    W, b = cbr('base.final_conv.1', 'base.final_conv.2')
+    f32 = P.tensor(256, 0)
+    P.conv(t, f32, W, b, act=ACT_RELU)
+    f8, f16 = feats
+    P.tap('feat8', f8, 0, 64)
+    P.tap('feat16', f16, 0, 128)
+    P.tap('feat32', f32, 0, 256)
+
+    e2 = arch.RETINA_REFINER_BN_EPS
+
+    def rcbr(p):
+        return cbr(p + '.0', p + '.1', e2, bias=True)
+
+    W, b = rcbr('refiner.conv_stride32')
+    p32 = P.tensor(64, 1, name='p32')
+    P.conv(f32, p32, W, b, act=ACT_RELU)
+    W, b = rcbr('refiner.conv_stride16')
+    s16 = P.tensor(64, 1)
+    P.conv(f16, s16, W, b, act=ACT_RELU, res=p32, res_up2=1)
+    W, b = rcbr('refiner.aggr_stride16')
+    p16 = P.tensor(64, 1, name='p16')
+    P.conv(s16, p16, W, b, act=ACT_RELU)
+    W, b = rcbr('refiner.conv_stride8')
+    s8 = P.tensor(64, 1)
+    P.conv(f8, s8, W, b, act=ACT_RELU, res=p16, res_up2=1)
+    W, b = rcbr('refiner.aggr_stride8')
+    p8 = P.tensor(64, 1, name='p8')
+    P.conv(s8, p8, W, b, act=ACT_RELU)
+
+    A = arch.RETINA_NUM_ANCHORS
+    heads = {}
+    for s, x in ((32, p32), (16, p16), (8, p8)):
+        p = 'refiner.context_stride%d' % s
+        ctx = P.tensor(96, 1)
+        W3, b3 = rcbr(p + '.context_3x3')
+        Wr, br_ = rcbr(p + '.dimension_reducer')
+        P.conv(x, ctx, np.concatenate([W3, Wr]), np.concatenate([b3, br_]), act=ACT_RELU, out_ch_off=0)
+        W5, b5 = rcbr(p + '.context_5x5')
+        W7, b7 = cbr(p + '.context_7x7.0', p + '.context_7x7.1', e2, bias=True)
+        P.conv(ctx, ctx, np.concatenate([W5, W7]), np.concatenate([b5, b7]), act=ACT_RELU, in_ch_off=32,
+               out_ch_off=48)
+        W7b, b7b = cbr(p + '.context_7x7.3', p + '.context_7x7.4', e2, bias=True)
+        P.conv(ctx, ctx, W7b, b7b, act=ACT_RELU, in_ch_off=64, out_ch_off=80)
+        P.tap('ctx%d_3x3' % s, ctx, 0, 32)
+        P.tap('ctx%d_5x5' % s, ctx, 48, 16)
+        P.tap('ctx%d_7x7' % s, ctx, 80, 16)
+        # merged heads: rows [cls 2A | bbox 4A | landmark 10A]; input order cat[3x3, 5x5, 7x7]
+        Wh = np.concatenate([sd['outputs.%s_stride%d.weight' % (h, s)] for h in ('cls', 'bbox', 'landmark')])
+        bh = np.concatenate([sd['outputs.%s_stride%d.bias' % (h, s)] for h in ('cls', 'bbox', 'landmark')])
+        pos = np.concatenate([np.arange(32), 48 + np.arange(16), 80 + np.arange(16)])
+        hd = P.tensor(16 * A, 0, name='head%d' % s)
+        P.conv(ctx, hd, Wh, bh, ch_pos=pos, cin_p=96)
+        heads[s] = hd
+    P.outputs = [heads[32], heads[16], heads[8]]
+    return P
+
+
+PACKERS = {MODEL_RETINAFACE: pack_retinaface, MODEL_ARCFACE: pack_arcface, MODEL_OPENPOSE: pack_openpose}

@@ -1,0 +1,112 @@
+"""-m gpu: unit tests of the implicit-GEMM conv kernel through a two-op program
+(uint8 frame -> 3x3 conv to C1 channels -> conv under test), against torch CPU conv2d."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from terran_amd import pack, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from terran_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+CASES = [
+    # c1, cout, k, stride, halo_in, in_off, cin_used, out_off, out_total, act, res, out2
+    dict(c1=128, cout=128, k=3),
+    dict(c1=128, cout=512, k=1),
+    dict(c1=128, cout=38, k=1, out_total=192, out_off=128, cout_p=40),
+    dict(c1=512, cout=19, k=1, out_total=192, out_off=168, cout_p=20),
+    dict(c1=128, cout=64, k=3, halo=3),
+    dict(c1=192, cout=128, k=7, halo=3),
+    dict(c1=192, cout=128, k=3, halo=3, in_off=0, cin_used=128),
+    dict(c1=64, cout=64, k=3, stride=2),
+    dict(c1=64, cout=128, k=1, stride=2, pad=0),
+    dict(c1=64, cout=16, k=3, in_off=32, cin_used=16),
+    dict(c1=8, cout=16, k=1),
+    dict(c1=16, cout=8, k=3),
+    dict(c1=64, cout=64, k=3, act=2, res=True, out2=True),
+    dict(c1=32, cout=32, k=1, act=1, res=True),
+    dict(c1=256, cout=256, k=3, n=3, h=14, w=14),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join('%s%s' % kv for kv in c.items()))
+def test_conv(ctx, case):
+    from terran_amd import lib
+    rng = np.random.default_rng(7)
+    c1, cout, k = case['c1'], case['cout'], case['k']
+    stride = case.get('stride', 1)
+    padv = case.get('pad', k // 2)
+    halo = case.get('halo', max(padv, 0))
+    in_off = case.get('in_off', 0)
+    cin_used = case.get('cin_used', c1)
+    out_off = case.get('out_off', 0)
+    out_total = case.get('out_total', (cout + 3) // 4 * 4)
+    act = case.get('act', 0)
+    n, h, w = case.get('n', 2), case.get('h', 19), case.get('w', 23)
+
+    P = pack.Program(pack.MODEL_OPENPOSE)
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    t1 = P.tensor(c1, halo, name='mid')
+    W1 = rng.normal(0, 0.3, (c1, 3, 3, 3)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, c1).astype(np.float32)
+    P.conv(t0, t1, W1, b1, act=pack.ACT_RELU)
+    W2 = rng.normal(0, 1.0 / np.sqrt(cin_used * k * k), (cout, cin_used, k, k)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, cout).astype(np.float32)
+    t2 = P.tensor(out_total, 0, name='out')
+    kw = {}
+    prelu = scale2 = shift2 = None
+    if act == 2:
+        prelu = rng.uniform(0.1, 0.4, cout).astype(np.float32)
+        kw['prelu'] = prelu
+    tres = -1
+    if case.get('res'):
+        # residual = a third tensor produced from the input by another conv (same spatial size as out)
+        tres = P.tensor((cout + 3) // 4 * 4, 0, name='res')
+        Wr = rng.normal(0, 0.3, (cout, 3, 3, 3)).astype(np.float32)
+        br = rng.normal(0, 0.1, cout).astype(np.float32)
+        P.conv(t0, tres, Wr, br, stride=stride, pad=1)
+        kw['res'] = tres
+    if case.get('out2'):
+        t3 = P.tensor((cout + 3) // 4 * 4, 1, name='out2')
+        scale2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift2 = rng.normal(0, 0.2, cout).astype(np.float32)
+        kw.update(out2=t3, scale2=scale2, shift2=shift2)
+    P.conv(t1, t2, W2, b2, stride=stride, pad=padv, act=act, in_ch_off=in_off, cin_p=cin_used,
+           out_ch_off=out_off, cout_p=case.get('cout_p'), **kw)
+    P.outputs = [t2]
+    m = lib.Model(ctx, P)
+
+    images = synth.frames(3, n, h, w)
+    m.forward_frames(ctx.upload(images))
+    x = torch.from_numpy(np.transpose(images, (0, 3, 1, 2)).astype(np.float32) / 255.0 - 0.5)
+    mid = F.relu(F.conv2d(x, torch.from_numpy(W1), torch.from_numpy(b1), padding=1))
+    np.testing.assert_allclose(m.read('mid'), mid.numpy(), rtol=1e-4, atol=1e-4)
+    y = F.conv2d(mid[:, in_off:in_off + cin_used], torch.from_numpy(W2), torch.from_numpy(b2), stride=stride,
+                 padding=padv)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.prelu(y, torch.from_numpy(prelu))
+    if case.get('res'):
+        r = F.conv2d(x, torch.from_numpy(Wr), torch.from_numpy(br), stride=stride, padding=1)
+        np.testing.assert_allclose(m.read('res')[:, :cout], r.numpy(), rtol=1e-4, atol=1e-4)
+        y = y + r
+    got = m.read('out')[:, out_off:out_off + cout]
+    np.testing.assert_allclose(got, y.numpy(), rtol=1e-4, atol=2e-4)
+    full = m.read('out')
+    mask = np.ones(out_total, bool)
+    mask[out_off:out_off + cout] = False
+    assert np.all(full[:, mask] == 0.0), 'conv wrote outside its channel slice'
+    if case.get('out2'):
+        z = y * torch.from_numpy(scale2)[None, :, None, None] + torch.from_numpy(shift2)[None, :, None, None]
+        np.testing.assert_allclose(m.read('out2')[:, :cout], z.numpy(), rtol=1e-4, atol=2e-4)

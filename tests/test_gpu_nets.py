@@ -1,0 +1,108 @@
+"""-m gpu: the three networks on the HIP path (through the C ABI) against the oracle.
+
+Float tolerance: rtol = atol = 1e-3 (BASELINE.json north_star: "within 1e-3 fp32"),
+scaled by the tensor's magnitude for un-normalised embeddings.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden
+from terran_amd import pack, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from terran_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def _close(a, b, tol=1e-3, what=''):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert err <= tol * scale, '%s: max abs err %.3e (scale %.3e)' % (what, err, scale)
+    return err
+
+
+def test_openpose_net(ctx, states):
+    from terran_amd import lib
+    from oracle import nets
+    sd = states('openpose')
+    m = lib.Model(ctx, pack.pack_openpose(sd))
+    g = golden('nets_openpose.npz')
+    for images in (g['images'], synth.frames(40, 2, 72, 104)):
+        fr = ctx.upload(images)
+        m.forward_frames(fr)
+        x = torch.from_numpy(np.transpose(images, (0, 3, 1, 2)).astype(np.float32) / 255.0 - 0.5)
+        taps = {}
+        paf, hm = nets.openpose_forward(sd, x, taps)
+        _close(m.read('feat'), taps['feat'].numpy(), what='feat')
+        # the stage tensors ping-pong between two concat buffers: only stage 5 (and 6) survive
+        _close(m.read('stage5_paf'), taps['stage5_paf'].numpy(), what='stage5 paf')
+        _close(m.read('stage5_hm'), taps['stage5_hm'].numpy(), what='stage5 hm')
+        e1 = _close(m.read('pafs'), paf.numpy(), what='pafs')
+        e2 = _close(m.read('heatmaps'), hm.numpy(), what='heatmaps')
+        print('openpose max err', e1, e2)
+    g_p, g_h = g['pafs'], g['heatmaps']
+    fr = ctx.upload(g['images'])
+    m.forward_frames(fr)
+    _close(m.read('pafs'), g_p, what='golden pafs')           # vs the reference module's own output
+    _close(m.read('heatmaps'), g_h, what='golden heatmaps')
+    assert m.read('heatmaps').min() >= 0.0                     # stage-6 heat-map ReLU quirk
+
+
+def test_arcface_net(ctx, states):
+    from terran_amd import lib
+    from oracle import nets
+    sd = states('arcface')
+    m = lib.Model(ctx, pack.pack_arcface(sd))
+    g = golden('nets_arcface.npz')
+    crops = np.concatenate([g['crops'], np.random.default_rng(41).integers(0, 256, (3, 3, 112, 112), dtype=np.uint8)])
+    m.forward_crops(crops)
+    taps = {}
+    emb = nets.arcface_forward(sd, torch.from_numpy(crops.astype(np.float32)), taps).numpy()
+    _close(m.read('stem'), taps['stem'].numpy(), what='stem')
+    for s in (1, 2, 3, 4):
+        _close(m.read('stage%d' % s), taps['stage%d' % s].numpy(), what='stage%d' % s)
+    out = m.read('embedding')[:, :, 0, 0]
+    e = _close(out, emb, what='embedding')
+    _close(out[:2], g['embeddings'], what='golden embedding')
+    print('arcface max err', e, 'scale', np.abs(emb).max())
+
+
+def test_retinaface_net(ctx, states):
+    from terran_amd import lib
+    from oracle import nets
+    sd = states('retinaface')
+    m = lib.Model(ctx, pack.pack_retinaface(sd))
+    g = golden('nets_retinaface.npz')
+    for images in (g['images'], synth.frames(42, 2, 75, 101)):      # odd sizes: ceil strides + upsample crop
+        fr = ctx.upload(images)
+        m.forward_frames(fr)
+        x = torch.from_numpy(images.astype(np.float32)).permute(0, 3, 1, 2).flip(1).contiguous()
+        taps = {}
+        outs = [o.numpy() for o in nets.retinaface_forward(sd, x, taps)]
+        _close(m.read('stem'), taps['stem'].numpy(), what='stem')
+        for s in (8, 16, 32):
+            _close(m.read('feat%d' % s), taps['feat%d' % s].numpy(), what='feat%d' % s)
+            _close(m.read('p%d' % s), taps['p%d' % s].numpy(), what='p%d' % s)
+            ctx_ref = taps['ctx%d' % s].numpy()
+            _close(m.read('ctx%d_3x3' % s), ctx_ref[:, :32], what='ctx3x3')
+            _close(m.read('ctx%d_5x5' % s), ctx_ref[:, 32:48], what='ctx5x5')
+            _close(m.read('ctx%d_7x7' % s), ctx_ref[:, 48:], what='ctx7x7')
+        for i, s in enumerate((32, 16, 8)):
+            head = m.read('head%d' % s)               # raw logits | bbox | landmarks
+            cls, bbox, lmk = head[:, 0:4], head[:, 4:12], head[:, 12:32]
+            prob = outs[3 * i]
+            ref_fg = prob[:, 2:4]
+            mine_fg = 1.0 / (1.0 + np.exp(cls[:, 0:2].astype(np.float64) - cls[:, 2:4].astype(np.float64)))
+            _close(mine_fg, ref_fg, what='fg prob s%d' % s)
+            _close(bbox, outs[3 * i + 1], what='bbox s%d' % s)
+            _close(lmk, outs[3 * i + 2], what='lmk s%d' % s)
