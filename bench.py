@@ -1,0 +1,194 @@
+"""bench.py -- end-to-end 1080p detect + embed + pose throughput on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[4], the configuration the metric is quoted on; it fits one GPU):
+a batch of B=32 synthetic 1080p RGB frames per GPU per step, ALREADY RESIDENT in HBM, through
+  Detection(short_side=416)  -> RetinaFace 416x739 + decode/NMS          (face/detection/__init__.py)
+  Recognition(top-F faces)   -> similarity warp + ArcFace-R100 + L2 norm   (face/recognition/__init__.py)
+  Estimation(short_side=184) -> OpenPose 184x327 + x8 bicubic + grouping   (pose/__init__.py)
+with random-init weights of the exact architectures (no checkpoints offline) and the full host
+side of the wrappers (result download, dict construction, landmark alignment math).
+One "step" = one such batch.  Frames shard embarrassingly: every rank owns its own batch, there
+is no data-path collective ("scaling": "weak").
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for `roofline` and `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+H, W = 1080, 1920
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
+    ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
+    ap.add_argument('--cpu-frames', type=int, default=4, help='frames in the bounded CPU-baseline sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
+
+    ctx = runtime.get_context(local_rank)
+    sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
+    det = Detection(short_side=416, device=local_rank, state=sd_r)
+    rec = Recognition(device=local_rank, state=sd_a)
+    est = Estimation(short_side=184, device=local_rank, state=sd_p)
+
+    frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
+    frames = ctx.upload(frames_host)                                # resident in HBM before timing
+    F = args.faces
+    fallback_lm = synth.landmarks(77, F, H, W)
+
+    def step():
+        dets = det(frames)
+        faces = []
+        for d in dets:
+            f = [{'landmarks': x['landmarks']} for x in d[:F]]
+            for k in range(len(f), F):                              # fewer than F detections: synthetic landmarks
+                f.append({'landmarks': fallback_lm[k]})
+            faces.append(f)
+        feats = rec.model.call(frames, faces)
+        poses = est(frames)
+        return dets, feats, poses
+
+    def sync():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (implicit-GEMM conv), HIP events on the launch stream ----
+    ctx.profile_reset()
+    ctx.profile(True)
+    step()
+    ctx.profile(False)
+    klass = {}
+    for k, name in enumerate(('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')):
+        ms, n, work = ctx.profile_read(k)
+        klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
+    conv = klass['conv_igemm']
+    achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        dets, feats, poses = out
+        total_frames = args.batch * args.steps * world
+        result = {
+            'metric': 'frames/sec 1080p detect+embed+pose',
+            'value': round(total_frames / elapsed, 3),
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[4]: 1080p frames, %d per GPU per step, resident in HBM; '
+                            'Detection(short_side=416) + Recognition(top-%d faces/frame) + '
+                            'Estimation(short_side=184); random-init weights (seeds 100/101/102)'
+                            % (args.batch, F),
+                'frames_per_gpu_step': args.batch,
+                'faces_per_frame': F,
+                'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
+                'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
+                'sharding': 'frames split over ranks, no data-path collective',
+            },
+            'roofline': {
+                'kernel': 'conv_igemm_f32 (v_mfma_f32_32x32x2_f32)',
+                'bound': 'mfma',
+                'achieved': round(achieved, 2),
+                'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                'traffic': None,
+                'launches_per_step': conv['launches'],
+                'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
+                'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
+            },
+            'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
+    frames.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
+    """The oracle (this repo's CPU restatement of Terran's path: torch-CPU fp32 nets + numpy
+    post-processing, pinned to the reference by tests/golden) on a bounded sample of the same
+    workload, all host cores.  kind = "port": the reference's Python cannot travel to the GPU box."""
+    import torch
+    from oracle import pipeline
+    n = len(frames_host)
+    t0 = time.perf_counter()
+    dets = pipeline.detection(sd_r, frames_host, short_side=416)
+    faces = []
+    for d in dets:
+        f = [{'landmarks': x['landmarks']} for x in d[:F]]
+        for k in range(len(f), F):
+            f.append({'landmarks': fallback_lm[k]})
+        faces.append(f)
+    pipeline.recognition(sd_a, list(frames_host), faces)
+    pipeline.estimation(sd_p, frames_host, short_side=184, bicubic_impl='torch')
+    dt = time.perf_counter() - t0
+    return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d of the same 1080p frames through oracle.pipeline detection+recognition(top-%d)+estimation '
+                      '(torch-CPU fp32, %.1f s)' % (n, F, dt)}
+
+
+if __name__ == '__main__':
+    main()

@@ -74,6 +74,9 @@ void ta_frames_free(ta_frames* f);
 /* cv2.resize(..., INTER_LINEAR) semantics on the device
  * (face/detection/__init__.py:33-38, pose/openpose/wrapper.py:106-111). */
 int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out);
+/* Pillow Image.resize(size, resample=BICUBIC) semantics (antialiased separable convolution with
+ * 22-bit fixed-point coefficients; arcface/wrapper.py:83-85, the no-landmark crop path). */
+int ta_frames_resize_bicubic(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out);
 /* Zero-pad `src` image `src_index` into image `dst_index` of `dst` at (top, left)
  * (merge_in, face/detection/__init__.py:96-139 / pose/__init__.py:48-88). */
 int ta_frames_paste(ta_ctx* ctx, const ta_frames* src, int src_index, ta_frames* dst, int dst_index,

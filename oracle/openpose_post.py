@@ -80,10 +80,18 @@ def _tap_chain(v, w):
     return r
 
 
-def bicubic_x8(x):
+def bicubic_x8(x, impl='numpy'):
     """x (..., h, w) float32 -> (..., 8h, 8w) float32.  Horizontal 4-tap chain on
-    each of the four source rows, then the same chain vertically."""
+    each of the four source rows, then the same chain vertically.
+
+    impl='torch' calls the reference's own op (F.interpolate bicubic) -- bit-identical to
+    the numpy restatement on the pinning machine, and what bench.py's cpu_baseline times."""
     x = np.asarray(x, dtype=F32)
+    if impl == 'torch':
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(x)).reshape((-1, 1) + x.shape[-2:])
+        up = torch.nn.functional.interpolate(t, scale_factor=8, mode='bicubic', align_corners=False)
+        return up.numpy().reshape(x.shape[:-2] + up.shape[-2:])
     h, w = x.shape[-2:]
     iy, wy = _axis_plan(h)
     ix, wx = _axis_plan(w)
@@ -263,8 +271,8 @@ def group_image(heatmaps_up, pafs_up, scale, debug=None):
     return keypoints_out(peaks_by_id, humans, scale)
 
 
-def postprocess(pafs, heatmaps, scale):
+def postprocess(pafs, heatmaps, scale, impl='numpy'):
     """Network outputs (N,38,h,w), (N,19,h,w) float32 -> list[N] of list[dict]."""
-    pafs_up = bicubic_x8(pafs)
-    hm_up = bicubic_x8(heatmaps)
+    pafs_up = bicubic_x8(pafs, impl)
+    hm_up = bicubic_x8(heatmaps, impl)
     return [group_image(hm_up[n], pafs_up[n], scale) for n in range(pafs.shape[0])]

@@ -45,11 +45,11 @@ def arcface_call(sd, images, faces_per_image=None):
     return out[0] if faces_per_image is None else out
 
 
-def openpose_call(sd, images, short_side=184):
+def openpose_call(sd, images, short_side=184, bicubic_impl='numpy'):
     resized, scale = facade.pose_resize(images, short_side)
     x = torch.from_numpy(np.transpose(resized, (0, 3, 1, 2)).astype(np.float32) / 255.0 - 0.5)
     pafs, hms = nets.openpose_forward(sd, x)
-    return openpose_post.postprocess(pafs.numpy(), hms.numpy(), scale)
+    return openpose_post.postprocess(pafs.numpy(), hms.numpy(), scale, bicubic_impl)
 
 
 # ---- facades ---------------------------------------------------------------------
@@ -82,11 +82,11 @@ def recognition(sd, images, faces_per_image=None):
     return out[0] if expanded else out
 
 
-def estimation(sd, images, short_side=184):
+def estimation(sd, images, short_side=184, bicubic_impl='numpy'):
     expanded = _is_single(images)
     if expanded:
         images = np.expand_dims(images, 0)
     images, mp = facade.merge_in(images)
-    out = openpose_call(sd, images, short_side)
+    out = openpose_call(sd, images, short_side, bicubic_impl)
     out = facade.pose_merge_out(out, mp)
     return out[0] if expanded else out

@@ -1,0 +1,120 @@
+"""`ArcFace` -- drop-in for terran/face/recognition/arcface/wrapper.py:102-184 on MI355X."""
+import numpy as np
+
+from . import lib, pack, runtime
+
+# Target landmark positions on the 112x112 crop: the 96x112 template with x shifted by 8,
+# built in float32 exactly like the reference does (arcface/wrapper.py:39-48).
+_TEMPLATE = np.array([[30.2946, 51.6963], [65.5318, 51.5014], [48.0252, 71.7366],
+                      [33.5493, 92.3655], [62.7299, 92.2041]], dtype=np.float32)
+_TEMPLATE[:, 0] += 8.0
+_IDENTITY = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
+
+
+def align_matrix(landmarks):
+    """Inverse 2x3 similarity (6 float64, PIL AFFINE convention) taking crop pixels to image
+    coordinates: least-squares similarity landmarks -> template (Umeyama; closed form in 2-D,
+    proper rotations only), inverted.  arcface/wrapper.py:50-61."""
+    p = np.asarray(landmarks).astype(np.float32).astype(np.float64)
+    q = _TEMPLATE.astype(np.float64)
+    pm, qm = p.mean(0), q.mean(0)
+    pd, qd = p - pm, q - qm
+    var = (pd * pd).sum() / p.shape[0]
+    a = (pd[:, 0] * qd[:, 0] + pd[:, 1] * qd[:, 1]).sum() / p.shape[0] / var     # s*cos
+    b = (pd[:, 0] * qd[:, 1] - pd[:, 1] * qd[:, 0]).sum() / p.shape[0] / var     # s*sin
+    R = np.array([[a, -b], [b, a]])
+    t = qm - R @ pm
+    T = np.eye(3)
+    T[:2, :2] = R
+    T[:2, 2] = t
+    return np.linalg.inv(T)[:2].reshape(6)
+
+
+class ArcFace:
+
+    def __init__(self, device=None, image_side=112, state=None):
+        if image_side != 112:
+            raise ValueError('the ArcFace-R100 head is a 25088->512 linear layer: image_side must be 112')
+        self.device = device
+        self.image_side = image_side
+        self.ctx = runtime.get_context(device)
+        self.model = lib.Model(self.ctx, pack.pack_arcface(runtime.resolve_state('arcface', state)))
+
+    # -- device entry points ---------------------------------------------------------------
+    def embed_crops(self, crops, normalize=True):
+        crops = np.ascontiguousarray(crops, dtype=np.uint8)
+        out = np.empty((crops.shape[0], 512), np.float32)
+        self.ctx.check(self.ctx.lib.ta_arcface_embed_crops(self.model.h, lib.ptr(crops), crops.shape[0],
+                                                           int(normalize), lib.ptr(out)))
+        return out
+
+    def embed_faces(self, frames, frame_index, matrices, normalize=True, return_crops=False):
+        """frames: lib.Frames; face k is cut from frames[frame_index[k]] with matrices[k] (6 doubles)."""
+        idx = np.ascontiguousarray(frame_index, dtype=np.int32)
+        mats = np.ascontiguousarray(matrices, dtype=np.float64).reshape(-1, 6)
+        n = idx.shape[0]
+        out = np.empty((n, 512), np.float32)
+        crops = np.empty((n, 3, 112, 112), np.uint8) if return_crops else None
+        self.ctx.check(self.ctx.lib.ta_arcface_embed_faces(self.model.h, frames.h, lib.ptr(idx), lib.ptr(mats), n,
+                                                           int(normalize), lib.ptr(out), lib.ptr(crops)))
+        return (out, crops) if return_crops else out
+
+    # -- the reference call ------------------------------------------------------------------
+    def call(self, images, faces_per_image=None):
+        """images: list of (H_i,W_i,3) uint8 RGB (or an (N,H,W,3) array); faces_per_image: list of
+        lists of dicts with 'landmarks'.  Returns a list with one float32 (N_i,512) L2-normalised
+        array per image, or a single array when `faces_per_image is None`."""
+        if isinstance(images, lib.Frames):          # resident batch: all faces in one device call
+            counts = [len(f) for f in faces_per_image]
+            if sum(counts) == 0:
+                return [np.empty((0, 512)) for _ in counts]
+            idx = [i for i, f in enumerate(faces_per_image) for _ in f]
+            mats = [align_matrix(face['landmarks']) for f in faces_per_image for face in f]
+            return np.split(self.embed_faces(images, idx, mats), np.cumsum(counts)[:-1], axis=0)
+        n_images = len(images)
+        if faces_per_image is not None:
+            counts = [len(f) for f in faces_per_image]
+            total = sum(counts)
+            if total == 0:
+                return [np.empty((0, 512)) for _ in range(n_images)]      # float64, as wrapper.py:160-164
+            feats = np.empty((total, 512), np.float32)
+            # one device batch per distinct image size (video batches: exactly one)
+            groups = {}
+            k = 0
+            for i, (image, faces) in enumerate(zip(images, faces_per_image)):
+                for face in faces:
+                    groups.setdefault(np.asarray(image).shape[:2], []).append((i, k, face))
+                    k += 1
+            for shape, items in groups.items():
+                img_ids = sorted({i for i, _, _ in items})
+                slot = {i: s for s, i in enumerate(img_ids)}
+                frames = self.ctx.upload(np.stack([np.asarray(images[i]) for i in img_ids]))
+                try:
+                    mats = [align_matrix(face['landmarks']) for _, _, face in items]
+                    out = self.embed_faces(frames, [slot[i] for i, _, _ in items], mats)
+                finally:
+                    frames.free()
+                feats[[kk for _, kk, _ in items]] = out
+            return np.split(feats, np.cumsum(counts)[:-1], axis=0)
+        if n_images == 0:
+            return []
+        # no landmarks: aspect-preserving Pillow-bicubic resize + centre pad (wrapper.py:75-99), on device
+        canvas = lib.Frames.zeros(self.ctx, n_images, 112, 112)
+        try:
+            for i, image in enumerate(images):
+                image = np.asarray(image)
+                h, w = image.shape[:2]
+                scale = 112 / max(w, h)
+                nw, nh = int(w * scale), int(h * scale)
+                src = self.ctx.upload(image[None])
+                try:
+                    small = src.resize_bicubic(nh, nw)
+                    try:
+                        canvas.paste(small, 0, i, int((112 - nh) / 2), int((112 - nw) / 2))
+                    finally:
+                        small.free()
+                finally:
+                    src.free()
+            return self.embed_faces(canvas, np.arange(n_images), np.tile(_IDENTITY, (n_images, 1)))
+        finally:
+            canvas.free()

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
       const int i = t / nd, j = t - i * nd;
       const int sy = syx[i * 2], sx = syx[i * 2 + 1], ty = dyx[j * 2], tx = dyx[j * 2 + 1];
       const float dyf = (float)(ty - sy), dxf = (float)(tx - sx);
-      const float norm = __fsqrt_rn(dyf * dyf + dxf * dxf);
+      // correctly rounded float sqrt (v_sqrt_f32 alone is 1 ulp): go through float64; the argument is an integer
+      const float norm = (float)sqrt((double)(dyf * dyf + dxf * dxf));
       const float uy = __fdiv_rn(dyf, norm), ux = __fdiv_rn(dxf, norm);
       const float ay = (float)sy, by = (float)ty, ax = (float)sx, bx = (float)tx;
       const float stepy = __fdiv_rn(by - ay, (float)(OP_NMID - 1)), stepx = __fdiv_rn(bx - ax, (float)(OP_NMID - 1));

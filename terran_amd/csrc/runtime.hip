@@ -225,6 +225,37 @@ __global__ __launch_bounds__(256) void paste_kernel(const uint8_t* src, int sh, 
   }
 }
 
+// Pillow ImagingResample pass along x: out[y][xx][c] = clip8((2^21 + sum_k src[y][xmin+k][c]*coef[xx][k]) >> 22).
+// `transpose` = 1 runs the same pass along y (src/dst indexed [x][y]).
+__global__ __launch_bounds__(256) void pil_resample_kernel(const uint8_t* src, int N, int H, int W, uint8_t* dst, int out_size,
+                                                            const int32_t* bounds, const int32_t* coef, int ksize, int vertical) {
+  const int oh = vertical ? out_size : H, ow = vertical ? W : out_size;
+  const size_t total = (size_t)N * oh * ow;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t pix = i;
+    const int x = (int)(pix % ow);
+    pix /= ow;
+    const int y = (int)(pix % oh);
+    const int img = (int)(pix / oh);
+    const int o = vertical ? y : x;
+    const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
+    const int32_t* k = coef + (size_t)o * ksize;
+    int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+    for (int t = 0; t < cnt; ++t) {
+      const uint8_t* s = vertical ? src + (((size_t)img * H + lo + t) * W + x) * 3 : src + (((size_t)img * H + y) * W + lo + t) * 3;
+      acc[0] += s[0] * k[t];
+      acc[1] += s[1] * k[t];
+      acc[2] += s[2] * k[t];
+    }
+    uint8_t* d = dst + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int v = acc[c] >> 22;
+      d[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+}
+
 #include <cmath>
 static void axis_table(int src, int dst, bool clamp_frac, std::vector<int32_t>& tab) {
   // mirrors oracle/facade.py:_axis_coeffs/_to_short (OpenCV resize.cpp semantics)
@@ -336,6 +367,94 @@ int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta
   }
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // pinned/scratch tables are reused by later calls
   return TA_OK;
+}
+
+static double pil_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+// mirrors oracle/arcface_pre.py:_resample_coeffs (Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc)
+static int pil_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& coef) {
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  coef.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      k[x] = pil_bicubic((x + xmin - center + 0.5) * ss);
+      ww += k[x];
+    }
+    for (int x = 0; x < xmax; ++x) {
+      double v = ww != 0.0 ? k[x] / ww : k[x];
+      coef[(size_t)xx * ksize + x] = v < 0 ? (int32_t)(-0.5 + v * (double)(1 << 22)) : (int32_t)(0.5 + v * (double)(1 << 22));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  return ksize;
+}
+
+static int pil_pass(ta_ctx* ctx, const uint8_t* src, int n, int h, int w, uint8_t* dst, int out_size, int vertical) {
+  std::vector<int32_t> bounds, coef;
+  const int ksize = pil_coeffs(vertical ? h : w, out_size, bounds, coef);
+  const size_t bb = bounds.size() * 4, cb = coef.size() * 4;
+  void* scr = nullptr;
+  TA_TRY(ta_scratch(ctx, bb + cb, &scr));
+  void* pin = nullptr;
+  TA_TRY(ta_pinned(ctx, bb + cb, &pin));
+  memcpy(pin, bounds.data(), bb);
+  memcpy((char*)pin + bb, coef.data(), cb);
+  TA_HIP(ctx, hipMemcpyAsync(scr, pin, bb + cb, hipMemcpyHostToDevice, ctx->stream));
+  const size_t total = (size_t)n * (vertical ? out_size : h) * (vertical ? w : out_size);
+  size_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(pil_resample_kernel, dim3((int)g), dim3(256), 0, ctx->stream, src, n, h, w, dst, out_size,
+                     (const int32_t*)scr, (const int32_t*)((char*)scr + bb), ksize, vertical);
+  TA_HIP(ctx, hipGetLastError());
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TA_OK;
+}
+
+int ta_frames_resize_bicubic(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out) {
+  if (!ctx || !src || !out || dst_h <= 0 || dst_w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_resize_bicubic: bad args");
+  // horizontal pass first, then vertical, each skipped when the size is unchanged (Pillow ImagingResample)
+  ta_frames* tmp = nullptr;
+  const uint8_t* cur = src->dev;
+  int cw = src->w;
+  if (dst_w != src->w) {
+    TA_TRY(ta_frames_alloc(ctx, src->n, src->h, dst_w, &tmp));
+    TA_TRY(pil_pass(ctx, cur, src->n, src->h, src->w, tmp->dev, dst_w, 0));
+    cur = tmp->dev;
+    cw = dst_w;
+  }
+  int rc = ta_frames_alloc(ctx, src->n, dst_h, dst_w, out);
+  if (rc == TA_OK) {
+    if (dst_h != src->h) {
+      rc = pil_pass(ctx, cur, src->n, src->h, cw, (*out)->dev, dst_h, 1);
+    } else {
+      hipError_t e = hipMemcpyAsync((*out)->dev, cur, (size_t)src->n * dst_h * dst_w * 3, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) rc = ta_fail(ctx, TA_E_DEVICE, "copy failed: %s", hipGetErrorString(e));
+      (void)hipStreamSynchronize(ctx->stream);
+    }
+  }
+  if (tmp) ta_frames_free(tmp);
+  return rc;
 }
 
 int ta_frames_paste(ta_ctx* ctx, const ta_frames* src, int src_index, ta_frames* dst, int dst_index, int top, int left) {

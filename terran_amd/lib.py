@@ -44,6 +44,7 @@ SIGNATURES = {
     'ta_frames_download': (c_int, [c_void_p, c_void_p]),
     'ta_frames_free': (None, [c_void_p]),
     'ta_frames_resize': (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_void_p)]),
+    'ta_frames_resize_bicubic': (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_void_p)]),
     'ta_frames_paste': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
     'ta_model_load': (c_int, [c_void_p, c_int, c_void_p, c_size_t, P(c_void_p)]),
     'ta_model_free': (None, [c_void_p]),
@@ -183,6 +184,9 @@ class Frames:
         ctx.lib.ta_frames_shape(self.h, C.byref(n), C.byref(hh), C.byref(ww))
         self.shape = (n.value, hh.value, ww.value, 3)
 
+    def __len__(self):
+        return self.shape[0]
+
     @classmethod
     def zeros(cls, ctx, n, h, w):
         hd = c_void_p()
@@ -192,6 +196,11 @@ class Frames:
     def resize(self, h, w):
         hd = c_void_p()
         self.ctx.check(self.ctx.lib.ta_frames_resize(self.ctx.h, self.h, int(h), int(w), C.byref(hd)))
+        return Frames(self.ctx, handle=hd)
+
+    def resize_bicubic(self, h, w):
+        hd = c_void_p()
+        self.ctx.check(self.ctx.lib.ta_frames_resize_bicubic(self.ctx.h, self.h, int(h), int(w), C.byref(hd)))
         return Frames(self.ctx, handle=hd)
 
     def paste(self, src, src_index, dst_index, top, left):

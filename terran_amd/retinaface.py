@@ -1,0 +1,80 @@
+"""`RetinaFace` -- drop-in for terran/face/detection/retinaface/wrapper.py:92-238 on MI355X."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib, pack, runtime
+
+
+class RetinaFace:
+
+    def __init__(self, device=None, nms_threshold=0.4, state=None):
+        self.device = device
+        self.nms_threshold = nms_threshold
+        self.ctx = runtime.get_context(device)
+        self.model = lib.Model(self.ctx, pack.pack_retinaface(runtime.resolve_state('retinaface', state)))
+
+    def call_frames(self, frames, threshold=0.5):
+        """frames: lib.Frames (N,H,W,3) at network resolution, resident in HBM."""
+        ctx = self.ctx
+        n = frames.shape[0]
+        if n == 0:
+            return []
+        counts = np.zeros(n, np.int32)
+        cap = max(256, 64 * n)
+        while True:
+            boxes = np.empty((cap, 4), np.float32)
+            lmks = np.empty((cap, 5, 2), np.float32)
+            scores = np.empty(cap, np.float32)
+            req = C.c_int32(0)
+            rc = ctx.lib.ta_retinaface_run(self.model.h, frames.h, float(threshold), float(self.nms_threshold), cap,
+                                           lib.ptr(counts), lib.ptr(boxes), lib.ptr(lmks), lib.ptr(scores),
+                                           C.byref(req))
+            if rc == lib.E_CAPACITY:
+                cap = int(req.value)
+                continue
+            ctx.check(rc)
+            break
+        out, o = [], 0
+        for c in counts:
+            out.append([{'bbox': boxes[i].copy(), 'landmarks': lmks[i].copy(), 'score': scores[i]}
+                        for i in range(o, o + int(c))])
+            o += int(c)
+        return out
+
+    def call(self, images, threshold=0.5):
+        """images: (N,H,W,3) uint8 RGB ndarray -> list[N] of list[{'bbox','landmarks','score'}] in
+        descending score order, network-input pixel coordinates."""
+        frames = self.ctx.upload(np.asarray(images))
+        try:
+            return self.call_frames(frames, threshold)
+        finally:
+            frames.free()
+
+
+def postprocess(ctx, outputs, H, W, threshold=0.5, nms_threshold=0.4):
+    """Debug/parity entry: the wrapper's decode + NMS tail on nine reference-layout head arrays."""
+    heads = [np.ascontiguousarray(o, dtype=np.float32) for o in outputs]
+    n = heads[0].shape[0]
+    arr = (C.c_void_p * 9)(*[h.ctypes.data for h in heads])
+    counts = np.zeros(max(n, 1), np.int32)
+    cap = 1024
+    while True:
+        boxes = np.empty((cap, 4), np.float32)
+        lmks = np.empty((cap, 5, 2), np.float32)
+        scores = np.empty(cap, np.float32)
+        req = C.c_int32(0)
+        rc = ctx.lib.ta_retinaface_postprocess(ctx.h, arr, n, int(H), int(W), float(threshold), float(nms_threshold),
+                                               cap, lib.ptr(counts), lib.ptr(boxes), lib.ptr(lmks), lib.ptr(scores),
+                                               C.byref(req))
+        if rc == lib.E_CAPACITY:
+            cap = int(req.value)
+            continue
+        ctx.check(rc)
+        break
+    out, o = [], 0
+    for c in counts[:n]:
+        out.append([{'bbox': boxes[i].copy(), 'landmarks': lmks[i].copy(), 'score': scores[i]}
+                    for i in range(o, o + int(c))])
+        o += int(c)
+    return out

@@ -1,0 +1,48 @@
+"""Process-wide device contexts and weight resolution for the wrapper classes."""
+import os
+
+import numpy as np
+
+from . import lib, weights
+
+_contexts = {}
+
+
+def device_index(device):
+    """Accepts None, an int, 'cuda', 'cuda:1', 'hip:1' or a torch.device."""
+    if device is None:
+        return int(os.environ.get('LOCAL_RANK', 0)) if os.environ.get('TERRAN_AMD_USE_LOCAL_RANK') else 0
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    s = str(device)
+    if s in ('cuda', 'hip', 'gpu'):
+        return 0
+    if ':' in s:
+        kind, idx = s.split(':', 1)
+        if kind in ('cuda', 'hip', 'gpu'):
+            return int(idx)
+    raise ValueError('terran_amd runs on MI355X only; cannot place a model on device %r' % (device,))
+
+
+def get_context(device=None):
+    idx = device_index(device)
+    ctx = _contexts.get(idx)
+    if ctx is None or ctx.h is None:
+        ctx = lib.Context(idx)
+        _contexts[idx] = ctx
+    return ctx
+
+
+def resolve_state(kind, state):
+    """state: None (look up the Terran checkpoint file), a path, or a {key: array} dict."""
+    if isinstance(state, dict):
+        return state
+    if isinstance(state, (str, os.PathLike)):
+        return weights.load_state(state)
+    from . import checkpoint
+    path = checkpoint.find_checkpoint_file(kind)
+    if path is not None:
+        return weights.load_state(path)
+    if os.environ.get('TERRAN_AMD_SYNTHETIC_WEIGHTS'):
+        return getattr(weights, 'make_%s_state' % kind)()
+    raise ValueError('Checkpoint not found.')     # same error as terran/checkpoint.py:242,310

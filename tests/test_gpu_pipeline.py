@@ -1,0 +1,285 @@
+"""-m gpu: post-processing kernels, wrapper classes and facades on the HIP path (through the
+C ABI) against the oracle and against the golden vectors the reference produced.
+
+Bars (BASELINE.json north_star): detection counts / order and keypoint assignments bit-exact;
+box coordinates, embeddings, scores within rtol = atol = 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden, unflatten
+from terran_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from terran_amd import runtime
+    return runtime.get_context(0)
+
+
+@pytest.fixture(scope='module')
+def det(states):
+    from terran_amd import RetinaFace
+    return RetinaFace(device=0, state=states('retinaface'))
+
+
+@pytest.fixture(scope='module')
+def arc(states):
+    from terran_amd import ArcFace
+    return ArcFace(device=0, state=states('arcface'))
+
+
+@pytest.fixture(scope='module')
+def pose(states):
+    from terran_amd import OpenPose
+    return OpenPose(device=0, short_side=64, state=states('openpose'))
+
+
+def _same_dets(got, ref, exact_scores=False):
+    assert [len(g) for g in got] == [len(r) for r in ref]
+    for g, r in zip(got, ref):
+        for a, b in zip(g, r):
+            np.testing.assert_allclose(a['bbox'], b['bbox'], **TOL)
+            np.testing.assert_allclose(a['landmarks'], b['landmarks'], **TOL)
+            if exact_scores:
+                assert a['score'] == b['score']
+            else:
+                np.testing.assert_allclose(a['score'], b['score'], **TOL)
+            assert a['bbox'].dtype == np.float32 and a['landmarks'].shape == (5, 2)
+
+
+# ---- RetinaFace ------------------------------------------------------------------------------
+def test_retinaface_postprocess_isolated(ctx, states):
+    """Decode + threshold + sort + NMS fed with the ORACLE's head tensors: selection must be identical."""
+    from oracle import nets, retinaface_post
+    from terran_amd import retinaface
+    imgs = synth.frames(0, 2, 208, 277)
+    x = torch.from_numpy(imgs.astype(np.float32)).permute(0, 3, 1, 2).flip(1).contiguous()
+    outs = [o.numpy() for o in nets.retinaface_forward(states('retinaface'), x)]
+    ref = retinaface_post.postprocess(outs, 208, 277)
+    got = retinaface.postprocess(ctx, outs, 208, 277)
+    assert sum(len(r) for r in ref) > 20
+    _same_dets(got, ref, exact_scores=True)
+
+
+def test_nms_bit_exact_synthetic(ctx):
+    """dw = dh = 0 makes exp() exact, so boxes and every IoU comparison are bit-identical: the kept
+    set and its order must match the oracle exactly, including score ties and threshold edges."""
+    from oracle import retinaface_post
+    from terran_amd import retinaface
+    rng = np.random.default_rng(5)
+    H, W, N = 96, 128, 3
+    heads = []
+    for s in (32, 16, 8):
+        fh, fw = -(-H // s), -(-W // s)
+        prob = rng.uniform(0, 1, (N, 4, fh, fw)).astype(np.float32)
+        prob[:, 2:][rng.uniform(size=(N, 2, fh, fw)) < 0.15] = 0.5          # exactly at the threshold
+        prob[:, 2:][rng.uniform(size=(N, 2, fh, fw)) < 0.10] = 0.75         # score ties
+        bbox = rng.normal(0, 0.35, (N, 8, fh, fw)).astype(np.float32)
+        bbox[:, [2, 3, 6, 7]] = 0.0
+        lmk = rng.normal(0, 0.3, (N, 20, fh, fw)).astype(np.float32)
+        heads += [prob, bbox, lmk]
+    ref = retinaface_post.postprocess(heads, H, W)
+    got = retinaface.postprocess(ctx, heads, H, W)
+    assert [len(g) for g in got] == [len(r) for r in ref] and sum(len(r) for r in ref) > 30
+    for g, r in zip(got, ref):
+        for a, b in zip(g, r):
+            assert np.array_equal(a['bbox'], b['bbox']) and a['score'] == b['score']
+            assert np.array_equal(a['landmarks'], b['landmarks'])
+    # edge cases: nothing above threshold / everything above threshold
+    heads[0][:, 2:] = 0.0
+    heads[3][:, 2:] = 0.0
+    heads[6][:, 2:] = 0.0
+    assert retinaface.postprocess(ctx, heads, H, W) == [[], [], []]
+    heads[6][:, 2:] = 0.9
+    ref = retinaface_post.postprocess(heads, H, W)
+    got = retinaface.postprocess(ctx, heads, H, W)
+    _same_dets(got, ref, exact_scores=True)
+
+
+def test_retinaface_call_vs_golden_and_oracle(det, states):
+    from oracle import pipeline
+    g = golden('retinaface_call.npz')
+    n, h, w = (int(v) for v in g['shape'])
+    frames = synth.frames(int(g['frames_seed']), n, h, w)
+    got = det.call(frames)
+    assert [len(d) for d in got] == g['counts'].tolist()          # counts bit-exact vs the REFERENCE
+    ref = unflatten(g['counts'], g['bbox'], g['landmarks'], g['score'])
+    for d, r in zip(got, ref):
+        for o, (bb, lm, sc) in zip(d, r):
+            np.testing.assert_allclose(o['bbox'], bb, **TOL)
+            np.testing.assert_allclose(o['landmarks'], lm, **TOL)
+            np.testing.assert_allclose(o['score'], sc, **TOL)
+    # odd sizes / batch of 3 vs the oracle
+    frames = synth.frames(9, 3, 101, 150)
+    _same_dets(det.call(frames), pipeline.retinaface_call(states('retinaface'), frames))
+    assert det.call(np.zeros((0, 64, 64, 3), np.uint8)) == []
+
+
+# ---- ArcFace ---------------------------------------------------------------------------------
+def test_arcface_call(arc, states):
+    from oracle import pipeline
+    g = golden('arcface_call.npz')
+    image, lms = g['image'], g['landmarks']
+    from terran_amd import arcface
+    frames = arc.ctx.upload(image[None])
+    feats, crops = arc.embed_faces(frames, [0, 0, 0], [arcface.align_matrix(l) for l in lms], return_crops=True)
+    assert np.array_equal(crops, g['crops'])                      # uint8 aligned crops bit-exact vs PIL
+    np.testing.assert_allclose(feats, g['features'], **TOL)       # vs the reference wrapper
+    out = arc.call([image], [[{'landmarks': l} for l in lms]])
+    assert len(out) == 1 and out[0].dtype == np.float32
+    np.testing.assert_allclose(out[0], g['features'], **TOL)
+    np.testing.assert_allclose(np.linalg.norm(out[0], axis=1), 1.0, atol=1e-5)
+    # no landmarks: Pillow-bicubic resize + pad on the device
+    small = image[:100, :80]
+    nolm = arc.call([small], None)
+    np.testing.assert_allclose(nolm, g['feature_nolm'], **TOL)
+    # empty: float64 (0,512) per image
+    empty = arc.call([image, image], [[], []])
+    assert [e.shape for e in empty] == [(0, 512), (0, 512)] and str(empty[0].dtype) == str(g['empty_dtype'])
+    # mixed image sizes, several faces, order preserved
+    img2 = synth.frames(8, 1, 90, 130)[0]
+    lm2 = synth.landmarks(12, 2, 90, 130)
+    faces = [[{'landmarks': lms[1]}], [{'landmarks': lm2[0]}, {'landmarks': lm2[1]}], [{'landmarks': lms[0]}]]
+    got = arc.call([image, img2, image], faces)
+    ref = pipeline.arcface_call(states('arcface'), [image, img2, image], faces)
+    assert [x.shape for x in got] == [x.shape for x in ref]
+    for a, b in zip(got, ref):
+        np.testing.assert_allclose(a, b, **TOL)
+
+
+def test_arcface_crops_and_cosine(arc, states, ctx):
+    from oracle import nets, arcface_pre
+    g = golden('nets_arcface.npz')
+    emb = arc.embed_crops(g['crops'], normalize=False)
+    np.testing.assert_allclose(emb, g['embeddings'], rtol=1e-3, atol=1e-3 * np.abs(g['embeddings']).max())
+    a = arcface_pre.l2_normalize(np.random.default_rng(1).normal(size=(5, 512)).astype(np.float32))
+    b = arcface_pre.l2_normalize(np.random.default_rng(2).normal(size=(7, 512)).astype(np.float32))
+    np.testing.assert_allclose(ctx.cosine_distance(a, b), arcface_pre.cosine_distance(a, b), atol=1e-6)
+    np.testing.assert_allclose(np.diag(ctx.cosine_distance(a, a)), 0.0, atol=1e-6)
+
+
+# ---- OpenPose --------------------------------------------------------------------------------
+def test_bicubic_bit_exact(ctx):
+    g = golden('bicubic.npz')
+    assert np.array_equal(ctx.bicubic_x8(g['maps']), g['up'])     # vs torch CPU F.interpolate
+
+
+def test_openpose_group_vs_reference(ctx):
+    """Grouping only, on synthetic maps: keypoint assignments bit-exact vs the REFERENCE wrapper."""
+    from terran_amd import openpose
+    g = golden('openpose_call.npz')
+    total = 0
+    for seed, P, h, w in g['cases']:
+        hm, paf = synth.pose_maps_batch(int(seed), 2, int(P), int(h), int(w))
+        poses = openpose.group(ctx, paf, hm, 1.0)
+        assert [len(p) for p in poses] == g['c%d_counts' % seed].tolist()
+        kp = np.array([o['keypoints'] for p in poses for o in p], np.int32).reshape(-1, 18, 3)
+        sc = np.array([o['score'] for p in poses for o in p], np.float64)
+        assert np.array_equal(kp, g['c%d_keypoints' % seed])
+        np.testing.assert_allclose(sc, g['c%d_scores' % seed], rtol=1e-6)
+        total += len(kp)
+    assert total > 50
+
+
+def test_openpose_group_vs_oracle_exact(ctx):
+    """Same maps through oracle and device: identical humans, scores to the last bit."""
+    from oracle import openpose_post
+    from terran_amd import openpose
+    for seed, P, h, w, scale in [(31, 5, 20, 28, 1.0), (32, 10, 24, 40, 0.37), (33, 2, 9, 11, 1.7)]:
+        hm, paf = synth.pose_maps_batch(seed, 3, P, h, w)
+        ref = openpose_post.postprocess(paf, hm, scale)
+        got = openpose.group(ctx, paf, hm, scale)
+        assert [len(p) for p in got] == [len(p) for p in ref]
+        for gp, rp in zip(got, ref):
+            for a, b in zip(gp, rp):
+                assert np.array_equal(a['keypoints'], b['keypoints']) and a['keypoints'].dtype == np.int32
+                assert a['score'] == b['score'] and isinstance(a['score'], np.float64)
+    # empty maps: no peaks at all
+    z = openpose.group(ctx, np.zeros((1, 38, 6, 8), np.float32), np.zeros((1, 19, 6, 8), np.float32), 1.0)
+    assert z == [[]]
+
+
+def test_openpose_call_vs_oracle(pose, states):
+    from oracle import pipeline
+    frames = synth.frames(7, 2, 96, 128)
+    ref = pipeline.openpose_call(states('openpose'), frames, short_side=64)
+    got = pose.call(frames)
+    assert [len(p) for p in got] == [len(p) for p in ref]
+    for gp, rp in zip(got, ref):
+        for a, b in zip(gp, rp):
+            assert np.array_equal(a['keypoints'], b['keypoints'])
+            np.testing.assert_allclose(a['score'], b['score'], rtol=1e-3)
+
+
+# ---- frames ----------------------------------------------------------------------------------
+def test_frames_resize_and_paste(ctx):
+    from oracle import facade, arcface_pre
+    from terran_amd import lib
+    imgs = synth.frames(3, 2, 97, 131)
+    fr = ctx.upload(imgs)
+    for (dh, dw) in [(64, 86), (208, 280), (97, 131), (33, 200)]:
+        out = fr.resize(dh, dw).download()
+        ref = np.stack([facade.cv2_resize_linear(im, (dw, dh)) for im in imgs])
+        assert np.array_equal(out, ref)                           # bit-exact vs the cv2 restatement
+    g = golden('pil_pins.npz')
+    src = ctx.upload(g['resize_in'][None])
+    assert np.array_equal(src.resize_bicubic(112, 70).download()[0], g['resize_out'])   # vs real Pillow
+    assert np.array_equal(src.resize_bicubic(40, 61).download()[0],
+                          arcface_pre.pil_resize_bicubic(g['resize_in'], (61, 40)))
+    canvas = lib.Frames.zeros(ctx, 2, 120, 140)
+    canvas.paste(fr, 1, 0, 12, 5)
+    c = canvas.download()
+    assert np.array_equal(c[0, 12:12 + 97, 5:5 + 131], imgs[1]) and c[1].sum() == 0 and c[0, :12].sum() == 0
+
+
+# ---- facades ---------------------------------------------------------------------------------
+def test_facade_detection_vs_reference(states):
+    from terran_amd import Detection
+    g = golden('facade_detection.npz')
+    frame = synth.frames(int(g['frame_seed']), 1, 480, 640)[0]
+    d = Detection(short_side=208, device=0, state=states('retinaface'))       # BASELINE configs[0]
+    res = d(frame)
+    assert len(res) == int(g['counts'][0]) and len(res) > 0
+    for o, bb, lm, sc in zip(res, g['bbox'], g['landmarks'], g['score']):
+        assert np.array_equal(o['bbox'], bb) and o['bbox'].dtype == np.int32
+        assert np.array_equal(o['landmarks'], lm) and o['landmarks'].dtype == np.int32
+        np.testing.assert_allclose(o['score'], sc, **TOL)
+    lst = d([frame[:400, :500], frame])
+    assert [len(x) for x in lst] == g['l_counts'].tolist()
+    for o, bb, lm in zip([o for x in lst for o in x], g['l_bbox'], g['l_landmarks']):
+        assert np.array_equal(o['bbox'], bb) and np.array_equal(o['landmarks'], lm)
+    with pytest.raises(NotImplementedError):
+        Detection(merge_method='crop', device=0, state=states('retinaface'))([frame, frame])
+
+
+def test_facade_pose_and_recognition_vs_reference(states):
+    from terran_amd import Estimation, Recognition
+    g = golden('facade_pose.npz')
+    f2 = synth.frames(int(g['frame_seed']), 1, 96, 128)[0]
+    e = Estimation(short_side=64, device=0, state=states('openpose'))
+    res = e([f2[:80, :100], f2])
+    assert [len(p) for p in res] == g['counts'].tolist()
+    kp = np.array([o['keypoints'] for p in res for o in p], np.int32).reshape(-1, 18, 3)
+    assert np.array_equal(kp, g['keypoints'])
+    np.testing.assert_allclose([o['score'] for p in res for o in p], g['scores'], rtol=1e-3)
+    single = e(f2)
+    assert isinstance(single, list) and (not single or isinstance(single[0], dict))
+
+    g = golden('facade_recognition.npz')
+    a = golden('arcface_call.npz')
+    image, lms = a['image'], a['landmarks']
+    rec = Recognition(device=0, state=states('arcface'))
+    one = rec(image, {'landmarks': lms[0]})
+    assert one.shape == (1, 512)
+    np.testing.assert_allclose(one, g['one'], **TOL)
+    np.testing.assert_allclose(rec(image, [{'landmarks': lms[0]}, {'landmarks': lms[1]}]), g['lst'], **TOL)
+    many = rec([image, image], [[{'landmarks': lms[0]}], []])
+    np.testing.assert_allclose(many[0], g['many0'], **TOL)
+    assert many[1].shape == (0, 512) and str(many[1].dtype) == str(g['many1_dtype'])
+    with pytest.raises(ValueError):
+        rec([image, image], [[]])
