@@ -1,0 +1,152 @@
+"""CPU tests (no GPU): C-ABI surface, host-side logic of the wrappers, sharding over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.util import REPO
+
+
+def test_abi_exports_every_declared_symbol():
+    """libterran_amd.so must export every function include/terran_amd.h declares, and the ctypes
+    table must bind exactly that set (no compute call: there is no GPU here)."""
+    from terran_amd import build, lib
+    path = build.build()
+    hdr = open(os.path.join(REPO, 'include', 'terran_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(ta_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 30
+    so = ctypes.CDLL(path)
+    for name in declared:
+        assert hasattr(so, name), 'missing ABI symbol %s' % name
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    lib.load()
+    so.ta_version.restype = ctypes.c_char_p
+    assert b'terran_amd' in so.ta_version()
+
+
+def test_no_gpu_fails_loudly():
+    """No CPU fallback: without a gfx950 device the product path raises (unless a GPU is present)."""
+    from terran_amd import lib
+    l = lib.load()
+    if l.ta_device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(lib.TerranAmdError):
+        lib.Context(0)
+    from terran_amd import RetinaFace
+    with pytest.raises(lib.TerranAmdError):
+        RetinaFace(device=0, state={})
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'terran_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_align_matrix_matches_umeyama():
+    from oracle import arcface_pre
+    from terran_amd import arcface, synth
+    for lm in synth.landmarks(3, 20, 480, 640):
+        np.testing.assert_allclose(arcface.align_matrix(lm), arcface_pre.align_matrix(lm), rtol=1e-9, atol=1e-9)
+    # reflected landmarks (det < 0 branch of Umeyama): still a proper rotation
+    lm = synth.landmarks(5, 1, 200, 200)[0]
+    lm[:, 0] = 200 - lm[:, 0]
+    np.testing.assert_allclose(arcface.align_matrix(lm), arcface_pre.align_matrix(lm), rtol=1e-8, atol=1e-8)
+
+
+def test_pads_match_reference_rule():
+    from oracle import facade as of
+    from terran_amd import facade
+    shapes = [(5, 7), (8, 4), (8, 7), (3, 3)]
+    mh, mw, pads = facade._pads(shapes)
+    imgs = [np.full(s + (3,), i + 1, np.uint8) for i, s in enumerate(shapes)]
+    padded, params = of.merge_in(imgs)
+    assert (mh, mw) == padded.shape[1:3]
+    for p, q in zip(pads, params['pads_per_image']):
+        assert (p[0], p[1]) == (q[0], q[1])
+
+
+def test_pack_programs_are_well_formed(states):
+    from terran_amd import pack
+    for kind, fn in (('openpose', pack.pack_openpose), ('arcface', pack.pack_arcface),
+                     ('retinaface', pack.pack_retinaface)):
+        P = fn(states(kind))
+        blob = P.blob()
+        hdr = np.frombuffer(blob[:128], pack.HEADER_DT)[0]
+        assert hdr['magic'] == pack.MAGIC and hdr['n_ops'] == len(P.ops)
+        assert hdr['weights_off'] % 256 == 0 and hdr['weights_off'] + hdr['weights_bytes'] == len(blob)
+        ops = np.frombuffer(blob[hdr['ops_off']:hdr['ops_off'] + 128 * len(P.ops)], pack.OP_DT)
+        conv = ops[ops['type'] == pack.OP_CONV]
+        assert np.all(conv['coutp'] % 32 == 0) and np.all(conv['cin'] % 4 == 0) and np.all(conv['n_slabs'] > 0)
+    # algorithmic MACs match SURVEY.md Appendix A (conv + linear, per image / crop)
+    def macs(P, h, w):
+        # walk shapes like the C++ planner does
+        dims = {P.input_tensor: (h, w)}
+        total = 0.0
+        for op in P.ops:
+            ih, iw = dims.get(op['in'], (1, 1)) if P.tensors[op['in']][2] < 0 else (1, 1)
+            if op['type'] in (pack.OP_CONV, pack.OP_DWCONV):
+                oh = (ih + 2 * op['pad'] - op['kh']) // op['stride'] + 1
+                ow = (iw + 2 * op['pad'] - op['kw']) // op['stride'] + 1
+                total += op['macs_per_pixel'] * oh * ow
+            elif op['type'] == pack.OP_MAXPOOL:
+                oh, ow = ih // 2, iw // 2
+            else:
+                oh, ow = ih, iw
+            dims[op['out']] = (oh, ow)
+            if op['out2'] >= 0:
+                dims[op['out2']] = (oh, ow)
+        return total
+    assert abs(macs(pack.pack_openpose(states('openpose')), 368, 656) / 242.32e9 - 1) < 2e-3
+    assert abs(macs(pack.pack_arcface(states('arcface')), 112, 112) / 12.090e9 - 1) < 2e-3
+    assert abs(macs(pack.pack_retinaface(states('retinaface')), 640, 640) / 981.1e6 - 1) < 5e-3
+
+
+def test_shard_bounds():
+    from terran_amd import shard
+    for n in (0, 1, 7, 32, 33):
+        for world in (1, 2, 4, 8):
+            spans = [shard.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from terran_amd import shard
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+frames = [np.full((4, 4, 3), i, np.uint8) for i in range(11)]
+def fn(fs):   # variable-length per-frame results, like detections
+    return [[{'id': int(f[0, 0, 0]), 'k': k} for k in range(int(f[0, 0, 0]) %% 3)] for f in fs]
+res = shard.run_sharded(frames, fn, dist)
+if dist.get_rank() == 0:
+    assert res == fn(frames), res          # 2-way result == 1-way result, order preserved
+    print('SHARD_OK')
+else:
+    assert res is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_gather_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'SHARD_OK' in outs[0]
