@@ -29,7 +29,15 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 H, W = 1080, 1920
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+# Dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md (spec): f32-input 157.3 TFLOP/s, bf16 2.5 PFLOP/s.
+# precision -> (peak of the MFMA opcode used, note, MFMA flops issued per algorithmic flop)
+PEAKS = {
+    'f32': (157.3, 'v_mfma_f32_32x32x2_f32 (exact f32)', 1),
+    'bf16x3': (2500.0, 'v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi, f32 accumulate)', 3),
+    'bf16': (2500.0, 'v_mfma_f32_32x32x16_bf16', 1),
+}
+DTYPES = {'f32': 'f32', 'bf16x3': 'f32 (activations/accumulators f32; products on split-bf16 MFMA, 3 per term)',
+          'bf16': 'bf16 (f32 accumulate)'}
 
 
 def main():
@@ -39,8 +47,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
-    ap.add_argument('--cpu-frames', type=int, default=4, help='frames in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-frames', type=int, default=16, help='frames in the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                    help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or bf16x3)')
+    ap.add_argument('--single-mode', action='store_true', help='skip the secondary f32-MFMA measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -61,59 +72,114 @@ def main():
 
     from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
 
+    # Two host threads per GPU, each with its own context (HIP stream + scratch): face path and pose path
+    # are independent per frame, so their kernels interleave on the device and the host-side result
+    # handling of one hides under the other's device time.
+    from concurrent.futures import ThreadPoolExecutor
     ctx = runtime.get_context(local_rank)
+    ctx_pose = runtime.new_context(local_rank)
     sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
-    det = Detection(short_side=416, device=local_rank, state=sd_r)
-    rec = Recognition(device=local_rank, state=sd_a)
-    est = Estimation(short_side=184, device=local_rank, state=sd_p)
-
+    pool = ThreadPoolExecutor(max_workers=1)
     frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
     frames = ctx.upload(frames_host)                                # resident in HBM before timing
+    frames_pose = ctx_pose.upload(frames_host)                      # the pose thread's handle on the batch
     F = args.faces
     fallback_lm = synth.landmarks(77, F, H, W)
 
-    def step():
-        dets = det(frames)
-        faces = []
-        for d in dets:
-            f = [{'landmarks': x['landmarks']} for x in d[:F]]
-            for k in range(len(f), F):                              # fewer than F detections: synthetic landmarks
-                f.append({'landmarks': fallback_lm[k]})
-            faces.append(f)
-        feats = rec.model.call(frames, faces)
-        poses = est(frames)
-        return dets, feats, poses
-
     def sync():
         ctx.sync()
+        ctx_pose.sync()
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_mode(precision):
+        """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then one serial
+        step with a HIP event pair around every launch for the per-kernel roofline."""
+        det = Detection(short_side=416, device=local_rank, state=sd_r, precision=precision)
+        rec = Recognition(device=local_rank, state=sd_a, precision=precision)
+        est = Estimation(short_side=184, device=local_rank, state=sd_p, ctx=ctx_pose, precision=precision)
 
-    # ---- roofline of the dominant kernel (implicit-GEMM conv), HIP events on the launch stream ----
-    ctx.profile_reset()
-    ctx.profile(True)
-    step()
-    ctx.profile(False)
-    klass = {}
-    for k, name in enumerate(('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')):
-        ms, n, work = ctx.profile_read(k)
-        klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
-    conv = klass['conv_igemm']
-    achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+        def face_path():
+            dets = det(frames)
+            faces = []
+            for d in dets:
+                f = [{'landmarks': x['landmarks']} for x in d[:F]]
+                for k in range(len(f), F):                          # fewer than F detections: synthetic landmarks
+                    f.append({'landmarks': fallback_lm[k]})
+                faces.append(f)
+            return dets, rec.model.call(frames, faces)
+
+        def step(concurrent=True):
+            if not concurrent:
+                dets, feats = face_path()
+                return dets, feats, est(frames_pose)
+            fut = pool.submit(est, frames_pose)
+            dets, feats = face_path()
+            return dets, feats, fut.result()
+
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        for c in (ctx, ctx_pose):
+            c.profile_reset()
+            c.profile(True)
+        step(concurrent=False)
+        klass = {}
+        for k, name in enumerate(('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')):
+            ms = n = work = 0
+            for c in (ctx, ctx_pose):
+                a, b, w_ = c.profile_read(k)
+                ms, n, work = ms + a, n + b, work + w_
+            klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
+        for c in (ctx, ctx_pose):
+            c.profile(False)
+        for m in (det.model, rec.model, est.model):
+            m.model.free()
+        return elapsed, out, klass
+
+    def roofline(precision, klass):
+        conv = klass['conv_igemm']
+        achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+        peak, note, factor = PEAKS[precision]
+        r = {
+            'kernel': 'conv_igemm / conv_igemm_pipe, %s' % note,
+            'bound': 'mfma',
+            'achieved': round(achieved, 2),
+            'peak': peak,
+            'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4),
+            'traffic': None,
+            'launches_per_step': conv['launches'],
+            'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
+            'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
+            'mfma_flops_per_algorithmic_flop': factor,
+            'mfma_issue_frac': round(achieved * factor / peak, 4),
+        }
+        pmc = os.path.join(REPO, 'profiles', 'pmc_conv_%s.json' % precision)
+        if os.path.exists(pmc):                       # rocprofv3 --pmc passes of this same command (profiles/README.md)
+            r['traffic'] = round(json.load(open(pmc))['hbm_bytes_per_launch'])
+            r['traffic_source'] = 'profiles/pmc_conv_%s.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % precision
+        return r
+
+    primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'bf16x3')
+    elapsed, out, klass = run_mode(primary)
+    others = {}
+    if not args.single_mode:
+        for prec in ('f32',):
+            if prec != primary:
+                e2, _, k2 = run_mode(prec)
+                others[prec] = {'value': round(args.batch * args.steps * world / e2, 3),
+                                'ms_per_step': round(e2 / args.steps * 1e3, 3), 'roofline': roofline(prec, k2)}
 
     result = None
     if rank == 0:
@@ -130,36 +196,30 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': DTYPES[primary],
             'data': 'synthetic',
             'config': {
                 'workload': 'BASELINE configs[4]: 1080p frames, %d per GPU per step, resident in HBM; '
                             'Detection(short_side=416) + Recognition(top-%d faces/frame) + '
                             'Estimation(short_side=184); random-init weights (seeds 100/101/102)'
                             % (args.batch, F),
+                'precision': primary,
                 'frames_per_gpu_step': args.batch,
                 'faces_per_frame': F,
                 'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
                 'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
                 'sharding': 'frames split over ranks, no data-path collective',
+                'streams_per_gpu': 2,
             },
-            'roofline': {
-                'kernel': 'conv_igemm_f32 (v_mfma_f32_32x32x2_f32)',
-                'bound': 'mfma',
-                'achieved': round(achieved, 2),
-                'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                'traffic': None,
-                'launches_per_step': conv['launches'],
-                'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
-                'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
-            },
+            'roofline': roofline(primary, klass),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
+            'other_precisions': others,
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
     frames.free()
+    frames_pose.free()
+    pool.shutdown()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,13 +32,14 @@ def align_matrix(landmarks):
 
 class ArcFace:
 
-    def __init__(self, device=None, image_side=112, state=None):
+    def __init__(self, device=None, image_side=112, state=None, ctx=None, precision=None):
         if image_side != 112:
             raise ValueError('the ArcFace-R100 head is a 25088->512 linear layer: image_side must be 112')
         self.device = device
+        self.precision = runtime.resolve_precision(precision)
         self.image_side = image_side
-        self.ctx = runtime.get_context(device)
-        self.model = lib.Model(self.ctx, pack.pack_arcface(runtime.resolve_state('arcface', state)))
+        self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
+        self.model = lib.Model(self.ctx, pack.pack_arcface(runtime.resolve_state('arcface', state), runtime.resolve_precision(precision)))
 
     # -- device entry points ---------------------------------------------------------------
     def embed_crops(self, crops, normalize=True):

@@ -106,6 +106,7 @@ static int embed_tail(ta_model* m, int n, int normalize, float* out) {
 extern "C" {
 
 int ta_arcface_embed_crops(ta_model* m, const uint8_t* crops, int n, int normalize, float* out) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || n < 0 || (n > 0 && (!crops || !out))) return TA_E_INVALID;
   if (m->kind != TA_MODEL_ARCFACE) return ta_fail(m->ctx, TA_E_INVALID, "arcface: wrong model kind");
   if (n == 0) return TA_OK;
@@ -115,6 +116,7 @@ int ta_arcface_embed_crops(ta_model* m, const uint8_t* crops, int n, int normali
 
 int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* frame_index, const double* inv_affine,
                            int n, int normalize, float* out, uint8_t* crops_out) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || !frames || n < 0 || (n > 0 && (!frame_index || !inv_affine || !out))) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_ARCFACE) return ta_fail(ctx, TA_E_INVALID, "arcface: wrong model kind");
@@ -145,6 +147,7 @@ int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* 
 }
 
 int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int nb, int dim, float* out) {
+  ta_enter(ctx);
   if (!ctx || na < 0 || nb < 0 || dim <= 0) return TA_E_INVALID;
   if (na == 0 || nb == 0) return TA_OK;
   if (!a || !b || !out) return ta_fail(ctx, TA_E_INVALID, "cosine: null pointer");

@@ -20,16 +20,137 @@
 // * MFMA rows are output channels, columns are pixels: each lane ends up with 4 consecutive
 //   channels of one pixel per accumulator quad -> 16-byte NHWC stores, fused bias / ReLU /
 //   PReLU / residual (optionally nearest-x2 upsampled) / second affine output.
+#include <stdlib.h>
+
 #include "ta_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Arithmetic modes of the MFMA inner loop (activations are float32 in HBM and LDS in every mode):
+//   PREC_F32    : v_mfma_f32_32x32x2_f32, exact f32 products.                          157 TF peak
+//   PREC_BF16X3 : x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
+//                 v_mfma_f32_32x32x16_bf16, f32 accumulate: ~1e-5 relative per product,
+//                 i.e. float32-class accuracy at 3/16 of the f32 MFMA cost.              833 TF-equivalent peak
+//   PREC_BF16   : hi*hi only (throughput mode, NOT within the 1e-3 parity bar).          2.5 PF peak
+// Weights are split at pack time ([hi x32 | lo x32] bf16 per 128-byte row); activation fragments are
+// split in registers right after the ds_read (v_cvt_pk_bf16_f32).
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ta_conv_launch p) {
+// Fused epilogue shared by both kernels.  acc[a][b][r]: pixel = tile col (lane&31);
+// cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the 32x32 tile.
+template <int WM_TILES, int WN_TILES>
+__device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&acc)[WM_TILES][WN_TILES], int co_tile0,
+                                              int pix_tile0, int lane, int HoWo) {
+  // ---- epilogue ------------------------------------------------------------------------------
+  // acc[a][b][r]: pixel = tile col (lane&31); cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the tile.
+  // Loads are grouped ahead of the math and only the stores are predicated, so the compiler can
+  // keep them all in flight instead of waiting per access.
+  const int co_base = co_tile0 + 4 * (lane >> 5);
+  f32x4 bias[WM_TILES][4];
+#pragma unroll
+  for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[a][j] = *(const f32x4*)(p.bias + co_base + a * 32 + 8 * j);   // padded to coutp
+  f32x4 slope[WM_TILES][4];
+  if (p.act == TA_ACT_PRELU) {
+#pragma unroll
+    for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) slope[a][j] = *(const f32x4*)(p.prelu + co_base + a * 32 + 8 * j);
+  }
+  const int co_max = p.cout - 4;
+#pragma unroll
+  for (int b = 0; b < WN_TILES; ++b) {
+    const int pix_raw = pix_tile0 + b * 32 + (lane & 31);
+    const bool pix_ok = pix_raw < p.M;
+    const int pix = pix_ok ? pix_raw : 0;
+    const int img = pix / HoWo;
+    const int rem = pix - img * HoWo;
+    const int y = rem / p.Wo;
+    const int x = rem - y * p.Wo;
+    f32x4 v[WM_TILES][4];
+#pragma unroll
+    for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[a][j][e] = acc[a][b][4 * j + e] + bias[a][j][e];
+    if (p.act == TA_ACT_RELU) {
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[a][j][e] = v[a][j][e] > 0.f ? v[a][j][e] : 0.f;
+    } else if (p.act == TA_ACT_PRELU) {
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[a][j][e] = v[a][j][e] > 0.f ? v[a][j][e] : v[a][j][e] * slope[a][j][e];
+    }
+    if (p.res) {
+      const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
+      const float* rs = p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0;
+      f32x4 r4[WM_TILES][4];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = co_base + a * 32 + 8 * j;
+          r4[a][j] = *(const f32x4*)(rs + (co < co_max ? co : co_max));   // clamped: masked at the store
+        }
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[a][j][e] += r4[a][j][e];
+    }
+    float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
+    if (pix_ok) {
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = co_base + a * 32 + 8 * j;
+          if (co < p.cout) *(f32x4*)(o + co) = v[a][j];
+        }
+    }
+    if (p.out2) {
+      float* o2 = p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0;
+      f32x4 sc[WM_TILES][4], sh[WM_TILES][4];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sc[a][j] = *(const f32x4*)(p.scale2 + co_base + a * 32 + 8 * j);   // padded to coutp
+          sh[a][j] = *(const f32x4*)(p.shift2 + co_base + a * 32 + 8 * j);
+        }
+      if (pix_ok) {
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int co = co_base + a * 32 + 8 * j;
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
+            if (co < p.cout) *(f32x4*)(o2 + co) = z;
+          }
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
+__global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;   // output channels per workgroup
   constexpr int BM = WAVES_N * WN_TILES * 32;   // pixels per workgroup
   constexpr int QA = BN / 32;                   // A-tile DMA instructions per wave per slab
@@ -131,128 +252,271 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ta_conv_launch p)
       if (s + 2 < S) kt_next = p.ktab[(s + 2) * 8 + lchunk];
     }
     const float* st = lds + (s & 1) * STAGE;
+    if constexpr (PREC == PREC_F32) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int pc = ((fcb + g) ^ fsw) * 4;
-      f32x4 av[WM_TILES], bv[WN_TILES];
+      for (int g = 0; g < 4; ++g) {
+        const int pc = ((fcb + g) ^ fsw) * 4;
+        f32x4 av[WM_TILES], bv[WN_TILES];
 #pragma unroll
-      for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+        for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
 #pragma unroll
-      for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+        for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+      }
+    } else {
+      // K-step t covers k = 16*kgrp + 8t + (0..7): weight chunk 2*kgrp+t (hi) / 4+2*kgrp+t (lo),
+      // activation float chunks kgrp*4 + 2t and kgrp*4 + 2t + 1.
+      const int kg = lane >> 5;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a) {
+          ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+          if constexpr (PREC == PREC_BF16X3) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) {
+          const f32x4 x0 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
+          const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+            bh[b][e] = h0;
+            bh[b][4 + e] = h1;
+            if constexpr (PREC == PREC_BF16X3) {
+              bl[b][e] = (__bf16)(x0[e] - (float)h0);
+              bl[b][4 + e] = (__bf16)(x1[e] - (float)h1);
+            }
+          }
+        }
+        if constexpr (PREC == PREC_BF16X3) {
+#pragma unroll
+          for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
           for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+      }
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------
-  // acc[a][b][r]: pixel = tile col (lane&31); cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the tile.
-  // Loads are grouped ahead of the math and only the stores are predicated, so the compiler can
-  // keep them all in flight instead of waiting per access.
-  const int co_base = ct0 + wm * WM_TILES * 32 + 4 * (lane >> 5);
-  f32x4 bias[WM_TILES][4];
+  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Deep-pipelined variant for convs whose K slabs never straddle a filter tap (cin % 32 == 0: every heavy
+// layer).  Differences from conv_igemm above:
+//  * the per-slab source offset is walked with scalar counters (channel block -> kx -> ky), so the K loop
+//    contains no ordinary global load at all (hipcc would otherwise drain the DMA queue with vmcnt(0) at
+//    the load's first use);
+//  * STAGES LDS buffers, raw s_barrier and a COUNTED s_waitcnt vmcnt(N): STAGES-1 slabs stay in flight
+//    across the barrier, which is what hides the L2/HBM latency once the MFMA work per slab shrinks
+//    (bf16x3 / bf16: 768 / 256 MFMA cycles per slab instead of 4096).
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES>
+__global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_TILES) * 32 * 128 <= 80 * 1024) ? 2 : 1) void conv_igemm_pipe(const ta_conv_launch p) {
+  constexpr int BN = WAVES_M * WM_TILES * 32;
+  constexpr int BM = WAVES_N * WN_TILES * 32;
+  constexpr int QA = BN / 32;
+  constexpr int QB = BM / 32;
+  constexpr int NI = QA + QB;                    // DMA instructions per wave per slab
+  constexpr int STAGE = (BN + BM) * 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  const int n_ct = p.coutp / BN;
+  const int bid = blockIdx.x;
+  const int grp = bid >> 3, xcd = bid & 7;
+  const int ct = grp % n_ct;
+  const int pt = (grp / n_ct) * 8 + xcd;
+  const int n_pt = (p.M + BM - 1) / BM;
+  if (pt >= n_pt) return;
+  const int ct0 = ct * BN;
+  const int pt0 = pt * BM;
+
+  const int pchunk = lane & 7;
+  const int lchunk = pchunk ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const int HoWo = p.Ho * p.Wo;
+
+  const char* a_src[QA];
 #pragma unroll
-  for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias[a][j] = *(const f32x4*)(p.bias + co_base + a * 32 + 8 * j);   // padded to coutp
-  f32x4 slope[WM_TILES][4];
-  if (p.act == TA_ACT_PRELU) {
-#pragma unroll
-    for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) slope[a][j] = *(const f32x4*)(p.prelu + co_base + a * 32 + 8 * j);
+  for (int q = 0; q < QA; ++q) {
+    const int row = (q * 4 + wave) * 8 + (lane >> 3);
+    a_src[q] = (const char*)(p.w + ((size_t)(ct0 + row)) * 32 + lchunk * 4);
   }
-  const int co_max = p.cout - 4;
+  const char* b_src[QB];
 #pragma unroll
-  for (int b = 0; b < WN_TILES; ++b) {
-    const int pix_raw = pt0 + wn * WN_TILES * 32 + b * 32 + (lane & 31);
-    const bool pix_ok = pix_raw < p.M;
-    const int pix = pix_ok ? pix_raw : 0;
+  for (int q = 0; q < QB; ++q) {
+    const int row = (q * 4 + wave) * 8 + (lane >> 3);
+    int pix = pt0 + row;
+    if (pix >= p.M) pix = 0;
     const int img = pix / HoWo;
     const int rem = pix - img * HoWo;
     const int y = rem / p.Wo;
     const int x = rem - y * p.Wo;
-    f32x4 v[WM_TILES][4];
-#pragma unroll
-    for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[a][j][e] = acc[a][b][4 * j + e] + bias[a][j][e];
-    if (p.act == TA_ACT_RELU) {
-#pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] = v[a][j][e] > 0.f ? v[a][j][e] : 0.f;
-    } else if (p.act == TA_ACT_PRELU) {
-#pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] = v[a][j][e] > 0.f ? v[a][j][e] : v[a][j][e] * slope[a][j][e];
+    const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row +
+                       (size_t)(x * p.stride) * p.in_pix + p.in_off0 + p.in_ch_off;
+    b_src[q] = (const char*)(p.in + off) + lchunk * 16;
+  }
+  const size_t a_slab_bytes = (size_t)p.coutp * 128;
+
+  // scalar walk over K: channel block (128 B) fastest, then kx, then ky
+  int k_cb = 0, k_x = 0;
+  int k_off = 0;                                  // byte offset of the next slab to issue
+  const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
+  auto advance = [&]() {
+    ++k_cb;
+    k_off += 128;
+    if (k_cb == p.k_cblocks) {
+      k_cb = 0;
+      k_off += pix_bytes - p.k_cblocks * 128;
+      if (++k_x == p.k_w) {
+        k_x = 0;
+        k_off += row_bytes - p.k_w * pix_bytes;
+      }
     }
-    if (p.res) {
-      const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
-      const float* rs = p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0;
-      f32x4 r4[WM_TILES][4];
+  };
+  auto issue = [&](int s, int stage) {
+    float* base = lds + stage * STAGE;
 #pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
+    for (int q = 0; q < QA; ++q) {
+      const int t = q * 4 + wave;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + (size_t)s * a_slab_bytes), LDS_PTR(base + t * 256), 16, 0, 0);
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int co = co_base + a * 32 + 8 * j;
-          r4[a][j] = *(const f32x4*)(rs + (co < co_max ? co : co_max));   // clamped: masked at the store
+    for (int q = 0; q < QB; ++q) {
+      const int t = q * 4 + wave;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[q] + k_off), LDS_PTR(base + BN * 32 + t * 256), 16, 0, 0);
+    }
+    advance();
+  };
+
+  f32x16 acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+    for (int b = 0; b < WN_TILES; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int fcb = (lane >> 5) * 4;
+  const int a_row0 = wm * WM_TILES * 32 + frow;
+  const int b_row0 = BN + wn * WN_TILES * 32 + frow;
+  const int kg = lane >> 5;
+
+  const int S = p.n_slabs;
+#pragma unroll
+  for (int i = 0; i < STAGES - 1; ++i)
+    if (i < S) issue(i, i);
+
+  int cur = 0;                  // stage holding slab s
+  int nxt = STAGES - 1;         // stage the next issue writes
+  for (int s = 0; s < S; ++s) {
+    // slab s must have landed; up to STAGES-2 younger slabs may stay in flight
+    const int ahead = (S - 1 - s) < (STAGES - 2) ? (S - 1 - s) : (STAGES - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + STAGES - 1 < S && p.ablate != 2) issue(s + STAGES - 1, nxt);
+    const float* st = lds + cur * STAGE;
+    if (p.ablate == 1) {
+      // tuning only: staging without compute
+    } else if constexpr (PREC == PREC_F32) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int pc = ((fcb + g) ^ fsw) * 4;
+        f32x4 av[WM_TILES], bv[WN_TILES];
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a) {
+          ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+          if constexpr (PREC == PREC_BF16X3) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
         }
 #pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
+        for (int b = 0; b < WN_TILES; ++b) {
+          const f32x4 x0 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
+          const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] += r4[a][j][e];
-    }
-    float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
-    if (pix_ok) {
-#pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int co = co_base + a * 32 + 8 * j;
-          if (co < p.cout) *(f32x4*)(o + co) = v[a][j];
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+            bh[b][e] = h0;
+            bh[b][4 + e] = h1;
+            if constexpr (PREC == PREC_BF16X3) {
+              bl[b][e] = (__bf16)(x0[e] - (float)h0);
+              bl[b][4 + e] = (__bf16)(x1[e] - (float)h1);
+            }
+          }
         }
-    }
-    if (p.out2) {
-      float* o2 = p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0;
-      f32x4 sc[WM_TILES][4], sh[WM_TILES][4];
+        if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
-      for (int a = 0; a < WM_TILES; ++a)
+          for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          sc[a][j] = *(const f32x4*)(p.scale2 + co_base + a * 32 + 8 * j);   // padded to coutp
-          sh[a][j] = *(const f32x4*)(p.shift2 + co_base + a * 32 + 8 * j);
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+            for (int b = 0; b < WN_TILES; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
         }
-      if (pix_ok) {
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int co = co_base + a * 32 + 8 * j;
-            f32x4 z;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
-            if (co < p.cout) *(f32x4*)(o2 + co) = z;
-          }
+          for (int b = 0; b < WN_TILES; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
       }
     }
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
   }
+
+  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
 }
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
   constexpr int BM = WAVES_N * WN_TILES * 32;
@@ -260,7 +524,7 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
-  auto kern = conv_igemm_f32<WAVES_M, WAVES_N, WM_TILES, WN_TILES>;
+  auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC>;
   static bool attr_set = false;
   if (!attr_set) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -272,11 +536,53 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   return TA_OK;
 }
 
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES>
+static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
+  constexpr int BN = WAVES_M * WM_TILES * 32;
+  constexpr int BM = WAVES_N * WN_TILES * 32;
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int groups = ((n_pt + 7) / 8) * n_ct;
+  const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
+  auto kern = conv_igemm_pipe<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+template <int PREC>
+static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
+  static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;   // tuning experiments only
+  if (p.uniform_k && p.n_slabs >= 2 && cfg != 9 && cfg != 1) {
+    if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3>(ctx, p);
+    if (cfg == 3 && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 4>(ctx, p);
+    if (cfg == 4 && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 2>(ctx, p);
+    if (cfg == 5 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 2>(ctx, p);
+    if (cfg == 6 && p.coutp % 128 == 0) return launch_pipe<1, 4, 4, 1, PREC, 2>(ctx, p);
+    if (cfg == 7 && p.coutp % 128 == 0) return launch_pipe<1, 4, 4, 1, PREC, 3>(ctx, p);
+    if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3>(ctx, p);
+  }
+  if (cfg == 1 && p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
+  if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2, PREC>(ctx, p);
+  if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
+  return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
+}
+
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
   if (p.M <= 0) return TA_OK;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
   ta_prof_scope scope(ctx, 0, flops);
-  if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2>(ctx, p);
-  if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1>(ctx, p);
-  return launch_cfg<1, 4, 1, 1>(ctx, p);
+  static const int ablate = getenv("TA_CONV_ABLATE") ? atoi(getenv("TA_CONV_ABLATE")) : 0;   // tuning only
+  const_cast<ta_conv_launch&>(p).ablate = ablate;
+  switch (p.prec) {
+    case PREC_F32: return launch_prec<PREC_F32>(ctx, p);
+    case PREC_BF16X3: return launch_prec<PREC_BF16X3>(ctx, p);
+    case PREC_BF16: return launch_prec<PREC_BF16>(ctx, p);
+  }
+  return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
 }

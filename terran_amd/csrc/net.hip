@@ -169,6 +169,11 @@ int ta_model_run_ops(ta_model* m) {
         p.cout = op.cout;
         p.act = op.act;
         p.stride = op.stride;
+        p.prec = op.prec;
+        p.uniform_k = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
+        p.k_cblocks = op.cin / 32;
+        p.k_w = op.kw;
+        p.in_ch_off = op.in_ch_off;
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;
         p.in_pix = ti.c;
@@ -237,6 +242,7 @@ int ta_model_run_ops(ta_model* m) {
 extern "C" {
 
 int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_model** out) {
+  ta_enter(ctx);
   if (!ctx || !blob || !out) return TA_E_INVALID;
   *out = nullptr;
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
@@ -294,6 +300,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
 }
 
 void ta_model_free(ta_model* m) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
   free_plan(m);
@@ -304,6 +311,7 @@ void ta_model_free(ta_model* m) {
 int ta_model_kind(const ta_model* m) { return m ? m->kind : TA_E_INVALID; }
 
 int ta_model_forward_frames(ta_model* m, const ta_frames* f) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || !f) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_RETINAFACE && m->kind != TA_MODEL_OPENPOSE)
@@ -316,6 +324,7 @@ int ta_model_forward_frames(ta_model* m, const ta_frames* f) {
 }
 
 int ta_model_forward_crops(ta_model* m, const uint8_t* crops, int n) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || (!crops && n > 0)) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_ARCFACE) return ta_fail(ctx, TA_E_INVALID, "forward_crops: not an ArcFace model");
@@ -342,6 +351,7 @@ int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* 
 }
 
 int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || !dst || tensor < 0 || tensor >= (int)m->tensors.size()) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   const ta_tensor& t = m->tensors[tensor];

@@ -574,6 +574,7 @@ extern "C" {
 
 int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capacity, int32_t* counts,
                     int32_t* keypoints, double* scores, int32_t* required) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || !frames || !counts) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_OPENPOSE) return ta_fail(ctx, TA_E_INVALID, "openpose_run: wrong model kind");
@@ -597,6 +598,7 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
 
 int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w, double scale,
                       int capacity, int32_t* counts, int32_t* keypoints, double* scores, int32_t* required) {
+  ta_enter(ctx);
   if (!ctx || n < 0 || h <= 0 || w <= 0 || !counts) return TA_E_INVALID;
   if (required) *required = 0;
   if (n == 0) return TA_OK;
@@ -623,6 +625,7 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
 }
 
 int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out) {
+  ta_enter(ctx);
   if (!ctx || n < 0 || c <= 0 || h <= 0 || w <= 0) return TA_E_INVALID;
   if (n == 0) return TA_OK;
   if (!maps || !out) return ta_fail(ctx, TA_E_INVALID, "bicubic: null pointer");

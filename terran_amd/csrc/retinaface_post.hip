@@ -316,6 +316,7 @@ extern "C" {
 
 int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, float nms_thr, int capacity,
                       int32_t* counts, float* boxes, float* landmarks, float* scores, int32_t* required) {
+  ta_enter(m ? m->ctx : nullptr);
   if (!m || !frames || !counts) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_RETINAFACE) return ta_fail(ctx, TA_E_INVALID, "retinaface_run: wrong model kind");
@@ -334,6 +335,7 @@ int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, flo
 int ta_retinaface_postprocess(ta_ctx* ctx, const float* const heads[9], int n, int h, int w, float score_thr,
                               float nms_thr, int capacity, int32_t* counts, float* boxes, float* landmarks,
                               float* scores, int32_t* required) {
+  ta_enter(ctx);
   if (!ctx || !heads || !counts || n < 0) return TA_E_INVALID;
   if (n == 0) {
     if (required) *required = 0;

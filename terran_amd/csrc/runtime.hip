@@ -131,12 +131,14 @@ void ta_ctx_destroy(ta_ctx* ctx) {
 const char* ta_last_error(const ta_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int ta_ctx_sync(ta_ctx* ctx) {
+  ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TA_OK;
 }
 
 int ta_profile_enable(ta_ctx* ctx, int on) {
+  ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
   if (!on) drain_profile(ctx);
   ctx->profiling = on != 0;
@@ -144,6 +146,7 @@ int ta_profile_enable(ta_ctx* ctx, int on) {
 }
 
 int ta_profile_reset(ta_ctx* ctx) {
+  ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
   drain_profile(ctx);
   for (auto& p : ctx->prof) p = ta_prof_class();
@@ -151,6 +154,7 @@ int ta_profile_reset(ta_ctx* ctx) {
 }
 
 int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, double* work) {
+  ta_enter(ctx);
   if (!ctx || klass < 0 || klass > 3) return TA_E_INVALID;
   drain_profile(ctx);
   if (ms) *ms = ctx->prof[klass].ms;
@@ -160,12 +164,14 @@ int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, doubl
 }
 
 int ta_timer_start(ta_ctx* ctx) {
+  ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
   TA_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
   return TA_OK;
 }
 
 int ta_timer_stop(ta_ctx* ctx, double* ms) {
+  ta_enter(ctx);
   if (!ctx || !ms) return TA_E_INVALID;
   TA_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
   TA_HIP(ctx, hipEventSynchronize(ctx->t1));
@@ -291,6 +297,7 @@ static void axis_table(int src, int dst, bool clamp_frac, std::vector<int32_t>& 
 extern "C" {
 
 int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
+  ta_enter(ctx);
   if (!ctx || !out || n < 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_alloc: bad shape");
   ta_frames* f = new ta_frames{ctx, n, h, w, nullptr};
   size_t bytes = (size_t)n * h * w * 3;
@@ -325,6 +332,7 @@ int ta_frames_shape(const ta_frames* f, int* n, int* h, int* w) {
 }
 
 int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb) {
+  ta_enter(f ? f->ctx : nullptr);
   if (!f || !nhwc_rgb) return TA_E_INVALID;
   ta_ctx* ctx = f->ctx;
   const size_t bytes = (size_t)f->n * f->h * f->w * 3;
@@ -336,6 +344,7 @@ int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb) {
 }
 
 void ta_frames_free(ta_frames* f) {
+  ta_enter(f ? f->ctx : nullptr);
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->dev) (void)hipFree(f->dev);
@@ -343,6 +352,7 @@ void ta_frames_free(ta_frames* f) {
 }
 
 int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out) {
+  ta_enter(ctx);
   if (!ctx || !src || !out || dst_h <= 0 || dst_w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_resize: bad args");
   TA_TRY(ta_frames_alloc(ctx, src->n, dst_h, dst_w, out));
   std::vector<int32_t> xt, yt;
@@ -432,6 +442,7 @@ static int pil_pass(ta_ctx* ctx, const uint8_t* src, int n, int h, int w, uint8_
 }
 
 int ta_frames_resize_bicubic(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out) {
+  ta_enter(ctx);
   if (!ctx || !src || !out || dst_h <= 0 || dst_w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_resize_bicubic: bad args");
   // horizontal pass first, then vertical, each skipped when the size is unchanged (Pillow ImagingResample)
   ta_frames* tmp = nullptr;
@@ -458,6 +469,7 @@ int ta_frames_resize_bicubic(ta_ctx* ctx, const ta_frames* src, int dst_h, int d
 }
 
 int ta_frames_paste(ta_ctx* ctx, const ta_frames* src, int src_index, ta_frames* dst, int dst_index, int top, int left) {
+  ta_enter(ctx);
   if (!ctx || !src || !dst || src_index < 0 || src_index >= src->n || dst_index < 0 || dst_index >= dst->n ||
       top < 0 || left < 0 || top + src->h > dst->h || left + src->w > dst->w)
     return ta_fail(ctx, TA_E_INVALID, "frames_paste: bad args");

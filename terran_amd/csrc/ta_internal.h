@@ -48,7 +48,7 @@ struct ta_op_desc {
   int32_t res, res_ch_off, res_up2;   // residual tensor (-1 none); res_up2: read residual at (y/2, x/2)
   int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
-  int32_t reserved;
+  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (f32-class), 2 = bf16 (throughput)
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
@@ -84,6 +84,10 @@ struct ta_ctx {
 };
 
 int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...);
+// HIP's current device is per host thread: every ABI entry point binds the calling thread to the ctx's GPU.
+static inline void ta_enter(const ta_ctx* ctx) {
+  if (ctx) (void)hipSetDevice(ctx->device);
+}
 int ta_scratch(ta_ctx* ctx, size_t bytes, void** out);   // device scratch, valid until next call
 int ta_pinned(ta_ctx* ctx, size_t bytes, void** out);    // pinned host staging
 
@@ -142,7 +146,9 @@ struct ta_conv_launch {
   float* out2;
   const float* scale2;
   const float* shift2;
-  int M, Ho, Wo, n_slabs, coutp, cout, act, stride;
+  int M, Ho, Wo, n_slabs, coutp, cout, act, stride, prec;
+  int ablate;                                  // tuning experiments only (0 in production)
+  int uniform_k, k_cblocks, k_w, in_ch_off;   // cin % 32 == 0: slabs walk (channel block, kx, ky) without a table
   // element strides / offsets
   int in_img, in_row, in_pix, in_off0;
   int out_img, out_row, out_pix, out_off0;

@@ -91,19 +91,25 @@ class Detection:
             for f in singles:
                 f.free()
         try:
-            out = self.model.call_frames(frames)
+            counts, boxes, lmks, scores = self.model.detect_arrays(frames)
         finally:
             frames.free()
-        if pads is not None:
-            out = [[{'bbox': np.array([f['bbox'][0] - p[1][0], f['bbox'][1] - p[0][0],
-                                       f['bbox'][2] - p[1][0], f['bbox'][3] - p[0][0]]),
-                     'landmarks': f['landmarks'] - np.array([p[1][0], p[0][0]]).reshape(1, -1),
-                     'score': f['score']} for f in faces] for faces, p in zip(out, pads)]
         if not isinstance(scales, list):
-            scales = [scales] * len(out)
-        out = [[{'bbox': np.around(f['bbox'] / s).astype(np.int32),
-                 'landmarks': np.around(f['landmarks'] / s).astype(np.int32),
-                 'score': f['score']} for f in faces] for faces, s in zip(out, scales)]
+            scales = [scales] * len(counts)
+        # un-pad and un-scale one image at a time (same element-wise arithmetic and dtypes as the
+        # reference's per-face code, face/detection/__init__.py:59-84,141-176), then hand out row views
+        out, o = [], 0
+        for i, c in enumerate(counts):
+            c = int(c)
+            b, l = boxes[o:o + c], lmks[o:o + c]
+            if pads is not None:
+                top, left = pads[i][0][0], pads[i][1][0]
+                b = b - np.array([left, top, left, top], np.float32)            # float32 - int stays float32
+                l = l - np.array([left, top]).reshape(1, 1, 2)                  # int64 array: promotes to float64
+            b = np.around(b / scales[i]).astype(np.int32)
+            l = np.around(l / scales[i]).astype(np.int32)
+            out.append([{'bbox': b[k], 'landmarks': l[k], 'score': scores[o + k]} for k in range(c)])
+            o += c
         return out[0] if expanded else out
 
 

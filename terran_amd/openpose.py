@@ -31,11 +31,12 @@ def _run(ctx, fn, n):
 
 class OpenPose:
 
-    def __init__(self, device=None, short_side=184, state=None):
+    def __init__(self, device=None, short_side=184, state=None, ctx=None, precision=None):
         self.device = device
+        self.precision = runtime.resolve_precision(precision)
         self.short_side = short_side
-        self.ctx = runtime.get_context(device)
-        self.model = lib.Model(self.ctx, pack.pack_openpose(runtime.resolve_state('openpose', state)))
+        self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
+        self.model = lib.Model(self.ctx, pack.pack_openpose(runtime.resolve_state('openpose', state), runtime.resolve_precision(precision)))
 
     def call_frames(self, frames):
         """frames: lib.Frames at ORIGINAL resolution; resized on the device to `short_side`."""

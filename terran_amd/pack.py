@@ -30,21 +30,45 @@ HEADER_DT = np.dtype({
 })
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('reserved', '<i4')])
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
-           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'reserved']
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 128 and TENSOR_DT.itemsize == 16
+
+
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
 
 
 def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+def _bf16_bits(x):
+    """float32 -> bfloat16 bit pattern (uint16), round to nearest even."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def _bf16_to_f32(b):
+    return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def split_bf16_rows(packed):
+    """[slab][cout][32] float32 -> the same 128-byte rows as [hi x32 | lo x32] bfloat16, returned as a
+    float32-typed view of the bytes (x = hi + lo to ~2^-17 relative)."""
+    hi = _bf16_bits(packed)
+    lo = _bf16_bits(packed - _bf16_to_f32(hi))
+    rows = np.concatenate([hi, lo], axis=-1)                # (..., 64) uint16
+    return np.ascontiguousarray(rows).view(np.float32)      # (..., 32)
+
+
 class Program:
     """Accumulates tensors, ops and the weight region of one model."""
 
-    def __init__(self, kind):
+    def __init__(self, kind, precision='f32'):
         self.kind = kind
+        self.precision = precision
+        self.prec = PRECISIONS[precision]
         self.tensors = []      # (channels, halo, alias_of)
         self.ops = []
         self.wchunks = []
@@ -97,6 +121,8 @@ class Program:
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:K] = full.reshape(K, coutp)
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
+        if self.prec != 0:
+            packed = split_bf16_rows(np.ascontiguousarray(packed))
 
         def vec(v):
             if v is None:
@@ -106,7 +132,7 @@ class Program:
             return self._w(out)
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
-                  res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, reserved=0,
+                  res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
                   w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
@@ -118,7 +144,7 @@ class Program:
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
-                  out2=-1, out2_ch_off=0, n_slabs=0, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
@@ -126,7 +152,7 @@ class Program:
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
-                  reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=0.0)
+                  prec=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)
 
@@ -172,10 +198,10 @@ def _fold(W, bias, scale, shift):
 OP_FEAT, OP_PAF, OP_HM, OP_XCH = 0, 128, 168, 192
 
 
-def pack_openpose(sd):
+def pack_openpose(sd, precision='f32'):
     """openpose/model.py:27-141.  Stage inputs cat[PAF, HM, feat] live in two ping-pong
     192-channel tensors; every stage-output conv writes its slice directly."""
-    P = Program(MODEL_OPENPOSE)
+    P = Program(MODEL_OPENPOSE, precision)
     t = P.tensor(4, 1, name='input')
     P.input_tensor = t
     X0 = P.tensor(OP_XCH, 3, name='X0')
@@ -233,12 +259,12 @@ def pack_openpose(sd):
 
 
 # ---- ArcFace -------------------------------------------------------------------------------
-def pack_arcface(sd):
+def pack_arcface(sd, precision='f32'):
     """arcface/model.py:4-97.  The residual stream R is kept raw (halo 0); each conv that
     closes a unit also emits Z = BN_next(R) (halo 1) for the next unit's first conv, so the
     pre-conv BatchNorm (model.py:12) is applied before zero padding exactly as the reference does."""
     eps = arch.ARC_BN_EPS
-    P = Program(MODEL_ARCFACE)
+    P = Program(MODEL_ARCFACE, precision)
     tin = P.tensor(4, 1, name='input')
     P.input_tensor = tin
     units = list(arch.arcface_units())
@@ -295,11 +321,11 @@ def pack_arcface(sd):
 # ---- RetinaFace ----------------------------------------------------------------------------
 # Context tensor channel layout (96): ctx3x3 0..31 | reducer 32..47 | ctx5x5 48..63 | 7x7-mid 64..79 |
 # ctx7x7 80..95; the merged head conv reads all 96 with zero weights on reducer / 7x7-mid.
-def pack_retinaface(sd):
+def pack_retinaface(sd, precision='f32'):
     """retinaface/model.py:53-316.  Sibling convs that share an input are merged (ctx3x3+reducer,
     ctx5x5+ctx7x7.0, cls+bbox+landmark heads); the FPN nearest-x2 upsample + add is the
     residual of the lateral 1x1 conv's epilogue."""
-    P = Program(MODEL_RETINAFACE)
+    P = Program(MODEL_RETINAFACE, precision)
     tin = P.tensor(4, 1, name='input')
     P.input_tensor = tin
     eps = arch.RETINA_BASE_BN_EPS

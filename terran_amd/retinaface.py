@@ -8,20 +8,21 @@ from . import lib, pack, runtime
 
 class RetinaFace:
 
-    def __init__(self, device=None, nms_threshold=0.4, state=None):
+    def __init__(self, device=None, nms_threshold=0.4, state=None, ctx=None, precision=None):
         self.device = device
+        self.precision = runtime.resolve_precision(precision)
         self.nms_threshold = nms_threshold
-        self.ctx = runtime.get_context(device)
-        self.model = lib.Model(self.ctx, pack.pack_retinaface(runtime.resolve_state('retinaface', state)))
+        self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
+        self.model = lib.Model(self.ctx, pack.pack_retinaface(runtime.resolve_state('retinaface', state), runtime.resolve_precision(precision)))
 
-    def call_frames(self, frames, threshold=0.5):
-        """frames: lib.Frames (N,H,W,3) at network resolution, resident in HBM."""
+    def detect_arrays(self, frames, threshold=0.5):
+        """-> (counts (N,) int32, boxes (T,4), landmarks (T,5,2), scores (T,)) float32, images concatenated."""
         ctx = self.ctx
         n = frames.shape[0]
-        if n == 0:
-            return []
         counts = np.zeros(n, np.int32)
-        cap = max(256, 64 * n)
+        if n == 0:
+            return counts, np.empty((0, 4), np.float32), np.empty((0, 5, 2), np.float32), np.empty(0, np.float32)
+        cap = getattr(self, '_cap', max(256, 64 * n))
         while True:
             boxes = np.empty((cap, 4), np.float32)
             lmks = np.empty((cap, 5, 2), np.float32)
@@ -31,14 +32,19 @@ class RetinaFace:
                                            lib.ptr(counts), lib.ptr(boxes), lib.ptr(lmks), lib.ptr(scores),
                                            C.byref(req))
             if rc == lib.E_CAPACITY:
-                cap = int(req.value)
+                cap = self._cap = int(req.value) * 5 // 4 + 64
                 continue
             ctx.check(rc)
             break
+        total = int(counts.sum())
+        return counts, boxes[:total], lmks[:total], scores[:total]
+
+    def call_frames(self, frames, threshold=0.5):
+        """frames: lib.Frames (N,H,W,3) at network resolution, resident in HBM."""
+        counts, boxes, lmks, scores = self.detect_arrays(frames, threshold)
         out, o = [], 0
         for c in counts:
-            out.append([{'bbox': boxes[i].copy(), 'landmarks': lmks[i].copy(), 'score': scores[i]}
-                        for i in range(o, o + int(c))])
+            out.append([{'bbox': boxes[i], 'landmarks': lmks[i], 'score': scores[i]} for i in range(o, o + int(c))])
             o += int(c)
         return out
 

@@ -33,6 +33,11 @@ def get_context(device=None):
     return ctx
 
 
+def new_context(device=None):
+    """An additional context (own HIP stream + scratch) on the same GPU, for a second host thread."""
+    return lib.Context(device_index(device))
+
+
 def resolve_state(kind, state):
     """state: None (look up the Terran checkpoint file), a path, or a {key: array} dict."""
     if isinstance(state, dict):
@@ -46,3 +51,12 @@ def resolve_state(kind, state):
     if os.environ.get('TERRAN_AMD_SYNTHETIC_WEIGHTS'):
         return getattr(weights, 'make_%s_state' % kind)()
     raise ValueError('Checkpoint not found.')     # same error as terran/checkpoint.py:242,310
+
+
+def resolve_precision(precision=None):
+    """'f32' (exact-f32 MFMA; the parity mode), 'bf16x3' (split-bf16 MFMA, float32-class accuracy) or
+    'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f32'."""
+    p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f32')
+    if p not in ('f32', 'bf16x3', 'bf16'):
+        raise ValueError('unknown precision %r' % (p,))
+    return p

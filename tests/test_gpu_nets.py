@@ -31,11 +31,15 @@ def _close(a, b, tol=1e-3, what=''):
     return err
 
 
-def test_openpose_net(ctx, states):
+PRECISIONS = ['f32', 'bf16x3']      # both must meet the 1e-3 bar; 'bf16' (throughput mode) is not expected to
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_openpose_net(ctx, states, precision):
     from terran_amd import lib
     from oracle import nets
     sd = states('openpose')
-    m = lib.Model(ctx, pack.pack_openpose(sd))
+    m = lib.Model(ctx, pack.pack_openpose(sd, precision))
     g = golden('nets_openpose.npz')
     for images in (g['images'], synth.frames(40, 2, 72, 104)):
         fr = ctx.upload(images)
@@ -49,7 +53,7 @@ def test_openpose_net(ctx, states):
         _close(m.read('stage5_hm'), taps['stage5_hm'].numpy(), what='stage5 hm')
         e1 = _close(m.read('pafs'), paf.numpy(), what='pafs')
         e2 = _close(m.read('heatmaps'), hm.numpy(), what='heatmaps')
-        print('openpose max err', e1, e2)
+        print('openpose', precision, 'max err', e1, e2)
     g_p, g_h = g['pafs'], g['heatmaps']
     fr = ctx.upload(g['images'])
     m.forward_frames(fr)
@@ -58,11 +62,12 @@ def test_openpose_net(ctx, states):
     assert m.read('heatmaps').min() >= 0.0                     # stage-6 heat-map ReLU quirk
 
 
-def test_arcface_net(ctx, states):
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_arcface_net(ctx, states, precision):
     from terran_amd import lib
     from oracle import nets
     sd = states('arcface')
-    m = lib.Model(ctx, pack.pack_arcface(sd))
+    m = lib.Model(ctx, pack.pack_arcface(sd, precision))
     g = golden('nets_arcface.npz')
     crops = np.concatenate([g['crops'], np.random.default_rng(41).integers(0, 256, (3, 3, 112, 112), dtype=np.uint8)])
     m.forward_crops(crops)
@@ -74,14 +79,15 @@ def test_arcface_net(ctx, states):
     out = m.read('embedding')[:, :, 0, 0]
     e = _close(out, emb, what='embedding')
     _close(out[:2], g['embeddings'], what='golden embedding')
-    print('arcface max err', e, 'scale', np.abs(emb).max())
+    print('arcface', precision, 'max err', e, 'scale', np.abs(emb).max())
 
 
-def test_retinaface_net(ctx, states):
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_retinaface_net(ctx, states, precision):
     from terran_amd import lib
     from oracle import nets
     sd = states('retinaface')
-    m = lib.Model(ctx, pack.pack_retinaface(sd))
+    m = lib.Model(ctx, pack.pack_retinaface(sd, precision))
     g = golden('nets_retinaface.npz')
     for images in (g['images'], synth.frames(42, 2, 75, 101)):      # odd sizes: ceil strides + upsample crop
         fr = ctx.upload(images)
