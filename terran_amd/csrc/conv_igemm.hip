@@ -67,12 +67,13 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
   for (int b = 0; b < WN_TILES; ++b) {
     const int pix_raw = pix_tile0 + b * 32 + (lane & 31);
-    const bool pix_ok = pix_raw < p.M;
-    const int pix = pix_ok ? pix_raw : 0;
-    const int img = pix / HoWo;
-    const int rem = pix - img * HoWo;
-    const int y = rem / p.Wo;
-    const int x = rem - y * p.Wo;
+    const int pixc = pix_raw < p.M ? pix_raw : 0;
+    const int img = pixc / HoWo;
+    const int rem = pixc - img * HoWo;
+    const int y = rem / p.Wq;
+    const int xr = rem - y * p.Wq;
+    const bool pix_ok = pix_raw < p.M && xr < p.Wo;      // Wq > Wo: row-run kernel computes (discarded) halo columns
+    const int x = xr < p.Wo ? xr : 0;
     f32x4 v[WM_TILES][4];
 #pragma unroll
     for (int a = 0; a < WM_TILES; ++a)
@@ -430,87 +431,154 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
   const int b_row0 = BN + wn * WN_TILES * 32 + frow;
   const int kg = lane >> 5;
 
-  const int S = p.n_slabs;
-#pragma unroll
-  for (int i = 0; i < STAGES - 1; ++i)
-    if (i < S) issue(i, i);
-
-  int cur = 0;                  // stage holding slab s
-  int nxt = STAGES - 1;         // stage the next issue writes
-  for (int s = 0; s < S; ++s) {
-    // slab s must have landed; up to STAGES-2 younger slabs may stay in flight
-    const int ahead = (S - 1 - s) < (STAGES - 2) ? (S - 1 - s) : (STAGES - 2);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (s + STAGES - 1 < S && p.ablate != 2) issue(s + STAGES - 1, nxt);
-    const float* st = lds + cur * STAGE;
-    if (p.ablate == 1) {
-      // tuning only: staging without compute
-    } else if constexpr (PREC == PREC_F32) {
+  // Register-level software pipeline on top of the LDS ring: while the MFMAs of slab s run from one
+  // fragment set, the other set is filled from LDS (ds_read_b128) and split into bf16 hi/lo for slab s+1,
+  // so matrix pipe, LDS and VALU of ONE wave overlap instead of serialising (measured additive before:
+  // MFMA 37 % + conversion 25 % + DMA 23 % + reads/barrier 36 % of a 7x7 layer).
+  struct Frag {
+    f32x4 a32[WM_TILES][4], b32[WN_TILES][4];                      // raw 16-byte chunks (f32 mode uses them directly)
+    bf16x8 ah[WM_TILES][2], al[WM_TILES][2], bh[WN_TILES][2], bl[WN_TILES][2];
+  };
+  auto load_raw = [&](Frag& f, const float* st) {
+    if constexpr (PREC == PREC_F32) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int pc = ((fcb + g) ^ fsw) * 4;
-        f32x4 av[WM_TILES], bv[WN_TILES];
 #pragma unroll
-        for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+        for (int a = 0; a < WM_TILES; ++a) f.a32[a][g] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
 #pragma unroll
-        for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+        for (int b = 0; b < WN_TILES; ++b) f.b32[b][g] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a) {
+          f.ah[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+          if constexpr (PREC == PREC_BF16X3) f.al[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) {
+          f.b32[b][2 * t] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
+          f.b32[b][2 * t + 1] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
+        }
+      }
+    }
+  };
+  auto convert = [&](Frag& f) {
+    if constexpr (PREC != PREC_F32) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = f.b32[b][2 * t][e], x1 = f.b32[b][2 * t + 1][e];
+            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+            f.bh[b][t][e] = h0;
+            f.bh[b][t][4 + e] = h1;
+            if constexpr (PREC == PREC_BF16X3) {
+              f.bl[b][t][e] = (__bf16)(x0 - (float)h0);
+              f.bl[b][t][4 + e] = (__bf16)(x1 - (float)h1);
+            }
+          }
+    }
+  };
+  auto mma = [&](const Frag& f) {
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
-      }
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a32[a][g][e], f.b32[b][g][e], acc[a][b], 0, 0, 0);
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
-#pragma unroll
-        for (int a = 0; a < WM_TILES; ++a) {
-          ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-          if constexpr (PREC == PREC_BF16X3) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
-        }
-#pragma unroll
-        for (int b = 0; b < WN_TILES; ++b) {
-          const f32x4 x0 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
-          const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
-            bh[b][e] = h0;
-            bh[b][4 + e] = h1;
-            if constexpr (PREC == PREC_BF16X3) {
-              bl[b][e] = (__bf16)(x0[e] - (float)h0);
-              bl[b][4 + e] = (__bf16)(x1[e] - (float)h1);
-            }
-          }
-        }
         if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[a][t], f.bh[b][t], acc[a][b], 0, 0, 0);
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a][t], f.bl[b][t], acc[a][b], 0, 0, 0);
         }
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
           for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a][t], f.bh[b][t], acc[a][b], 0, 0, 0);
       }
     }
-    cur = cur + 1 == STAGES ? 0 : cur + 1;
-    nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+  };
+
+  const int S = p.n_slabs;
+#pragma unroll
+  for (int i = 0; i < STAGES - 1; ++i)
+    if (i < S) issue(i, i);
+  // slab 0 -> fragment set X
+  {
+    const int ahead = (S - 1) < (STAGES - 2) ? (S - 1) : (STAGES - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (STAGES - 1 < S) issue(STAGES - 1, STAGES - 1);
+  }
+  Frag X, Y;
+  load_raw(X, lds);
+  convert(X);
+  int nxt_stage = 1;              // LDS stage of slab s+1
+  int free_stage = 0;             // stage of slab s: free once every wave has loaded its fragments
+  // one step (s + 1 < S): fragments of slab s are in `cur`; bring slab s+1 into `nxt` under the MFMAs of slab s.
+  // Everything after the issue is one straight-line block so the scheduler can interleave it.
+  auto step = [&](Frag& cur, Frag& nxt, int s) {
+    const int rem = S - 2 - s;                         // slabs younger than s+1 that exist
+    const int ahead = rem < (STAGES - 2) ? rem : (STAGES - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // slab s+1 visible; all waves are done reading slab s from LDS
+    asm volatile("" ::: "memory");
+    if (s + STAGES < S) issue(s + STAGES, free_stage);
+    __builtin_amdgcn_sched_barrier(0);
+    load_raw(nxt, lds + nxt_stage * STAGE);
+    mma(cur);
+    convert(nxt);
+    if constexpr (PREC != PREC_F32) {
+      // hipcc otherwise emits the MFMAs back to back and the hi/lo split after them: pin an interleave
+      // (all fragment reads first, then 1 MFMA : VPM VALU) so the split runs in the MFMA shadows.
+      constexpr int NREAD = 2 * (WM_TILES * (PREC == PREC_BF16X3 ? 2 : 1) + 2 * WN_TILES);
+      constexpr int NMFMA = 2 * WM_TILES * WN_TILES * (PREC == PREC_BF16X3 ? 3 : 1);
+      constexpr int VPM = (PREC == PREC_BF16X3 ? 58 : 30) * WN_TILES / NMFMA + 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+#pragma unroll
+      for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+      }
+    }
+    free_stage = nxt_stage;
+    nxt_stage = nxt_stage + 1 == STAGES ? 0 : nxt_stage + 1;
+  };
+  int s = 0;
+  for (; s + 2 < S; s += 2) {
+    step(X, Y, s);
+    step(Y, X, s + 1);
+  }
+  if (s + 1 < S) {          // S - s == 2
+    step(X, Y, s);
+    mma(Y);
+  } else {                  // S - s == 1
+    mma(X);
   }
 
   conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
@@ -557,17 +625,12 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
 
 template <int PREC>
 static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
-  static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;   // tuning experiments only
-  if (p.uniform_k && p.n_slabs >= 2 && cfg != 9 && cfg != 1) {
+  // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles)
+  static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
+  if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
     if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3>(ctx, p);
-    if (cfg == 3 && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 4>(ctx, p);
-    if (cfg == 4 && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 2>(ctx, p);
-    if (cfg == 5 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 2>(ctx, p);
-    if (cfg == 6 && p.coutp % 128 == 0) return launch_pipe<1, 4, 4, 1, PREC, 2>(ctx, p);
-    if (cfg == 7 && p.coutp % 128 == 0) return launch_pipe<1, 4, 4, 1, PREC, 3>(ctx, p);
     if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3>(ctx, p);
   }
-  if (cfg == 1 && p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
   if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2, PREC>(ctx, p);
   if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
   return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
@@ -577,8 +640,6 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
   if (p.M <= 0) return TA_OK;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
   ta_prof_scope scope(ctx, 0, flops);
-  static const int ablate = getenv("TA_CONV_ABLATE") ? atoi(getenv("TA_CONV_ABLATE")) : 0;   // tuning only
-  const_cast<ta_conv_launch&>(p).ablate = ablate;
   switch (p.prec) {
     case PREC_F32: return launch_prec<PREC_F32>(ctx, p);
     case PREC_BF16X3: return launch_prec<PREC_BF16X3>(ctx, p);

@@ -147,8 +147,8 @@ struct ta_conv_launch {
   const float* scale2;
   const float* shift2;
   int M, Ho, Wo, n_slabs, coutp, cout, act, stride, prec;
-  int ablate;                                  // tuning experiments only (0 in production)
-  int uniform_k, k_cblocks, k_w, in_ch_off;   // cin % 32 == 0: slabs walk (channel block, kx, ky) without a table
+  int uniform_k, k_cblocks, k_w, k_h, in_ch_off;
+  int Wq;                                      // pixel decomposition width (== Wo except in the row-run kernel)   // cin % 32 == 0: slabs walk (channel block, kx, ky) without a table
   // element strides / offsets
   int in_img, in_row, in_pix, in_off0;
   int out_img, out_row, out_pix, out_off0;
