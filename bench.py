@@ -64,11 +64,19 @@ def main():
 
     import torch
     dist = None
+    # RCCL (backend "nccl") on the GPU box; TA_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a
+    # single-GPU box (ranks then share device LOCAL_RANK % device_count).
+    backend = os.environ.get('TA_BENCH_BACKEND', 'nccl')
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            torch.cuda.set_device(device_index)
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', device_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
 
@@ -76,8 +84,8 @@ def main():
     # are independent per frame, so their kernels interleave on the device and the host-side result
     # handling of one hides under the other's device time.
     from concurrent.futures import ThreadPoolExecutor
-    ctx = runtime.get_context(local_rank)
-    ctx_pose = runtime.new_context(local_rank)
+    ctx = runtime.get_context(device_index)
+    ctx_pose = runtime.new_context(device_index)
     sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
     pool = ThreadPoolExecutor(max_workers=1)
     frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
@@ -90,15 +98,16 @@ def main():
         ctx.sync()
         ctx_pose.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if backend == 'nccl':
+                torch.cuda.synchronize()
             dist.barrier()
 
     def run_mode(precision):
         """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then one serial
         step with a HIP event pair around every launch for the per-kernel roofline."""
-        det = Detection(short_side=416, device=local_rank, state=sd_r, precision=precision)
-        rec = Recognition(device=local_rank, state=sd_a, precision=precision)
-        est = Estimation(short_side=184, device=local_rank, state=sd_p, ctx=ctx_pose, precision=precision)
+        det = Detection(short_side=416, device=device_index, state=sd_r, precision=precision)
+        rec = Recognition(device=device_index, state=sd_a, precision=precision)
+        est = Estimation(short_side=184, device=device_index, state=sd_p, ctx=ctx_pose, precision=precision)
 
         def face_path():
             dets = det(frames)
@@ -127,7 +136,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         for c in (ctx, ctx_pose):

@@ -21,22 +21,28 @@ def ctx():
     return runtime.get_context(0)
 
 
+@pytest.fixture(scope='module', params=['f32', 'bf16x3'])
+def precision(request):
+    """Both parity-grade conv modes must pass every wrapper / facade test (bf16x3 is bench.py's headline mode)."""
+    return request.param
+
+
 @pytest.fixture(scope='module')
-def det(states):
+def det(states, precision):
     from terran_amd import RetinaFace
-    return RetinaFace(device=0, state=states('retinaface'))
+    return RetinaFace(device=0, state=states('retinaface'), precision=precision)
 
 
 @pytest.fixture(scope='module')
-def arc(states):
+def arc(states, precision):
     from terran_amd import ArcFace
-    return ArcFace(device=0, state=states('arcface'))
+    return ArcFace(device=0, state=states('arcface'), precision=precision)
 
 
 @pytest.fixture(scope='module')
-def pose(states):
+def pose(states, precision):
     from terran_amd import OpenPose
-    return OpenPose(device=0, short_side=64, state=states('openpose'))
+    return OpenPose(device=0, short_side=64, state=states('openpose'), precision=precision)
 
 
 def _same_dets(got, ref, exact_scores=False):
@@ -238,11 +244,11 @@ def test_frames_resize_and_paste(ctx):
 
 
 # ---- facades ---------------------------------------------------------------------------------
-def test_facade_detection_vs_reference(states):
+def test_facade_detection_vs_reference(states, precision):
     from terran_amd import Detection
     g = golden('facade_detection.npz')
     frame = synth.frames(int(g['frame_seed']), 1, 480, 640)[0]
-    d = Detection(short_side=208, device=0, state=states('retinaface'))       # BASELINE configs[0]
+    d = Detection(short_side=208, device=0, state=states('retinaface'), precision=precision)   # BASELINE configs[0]
     res = d(frame)
     assert len(res) == int(g['counts'][0]) and len(res) > 0
     for o, bb, lm, sc in zip(res, g['bbox'], g['landmarks'], g['score']):
@@ -257,11 +263,11 @@ def test_facade_detection_vs_reference(states):
         Detection(merge_method='crop', device=0, state=states('retinaface'))([frame, frame])
 
 
-def test_facade_pose_and_recognition_vs_reference(states):
+def test_facade_pose_and_recognition_vs_reference(states, precision):
     from terran_amd import Estimation, Recognition
     g = golden('facade_pose.npz')
     f2 = synth.frames(int(g['frame_seed']), 1, 96, 128)[0]
-    e = Estimation(short_side=64, device=0, state=states('openpose'))
+    e = Estimation(short_side=64, device=0, state=states('openpose'), precision=precision)
     res = e([f2[:80, :100], f2])
     assert [len(p) for p in res] == g['counts'].tolist()
     kp = np.array([o['keypoints'] for p in res for o in p], np.int32).reshape(-1, 18, 3)
@@ -273,7 +279,7 @@ def test_facade_pose_and_recognition_vs_reference(states):
     g = golden('facade_recognition.npz')
     a = golden('arcface_call.npz')
     image, lms = a['image'], a['landmarks']
-    rec = Recognition(device=0, state=states('arcface'))
+    rec = Recognition(device=0, state=states('arcface'), precision=precision)
     one = rec(image, {'landmarks': lms[0]})
     assert one.shape == (1, 512)
     np.testing.assert_allclose(one, g['one'], **TOL)
