@@ -64,6 +64,11 @@ int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, doubl
 int ta_timer_start(ta_ctx* ctx);
 int ta_timer_stop(ta_ctx* ctx, double* ms);
 
+/* Pinned (page-locked) host memory for staging frame batches: H2D copies from it run at full PCIe rate and
+ * overlap with kernels of other contexts (terran/io/video/reader.py:88-117 hands over pageable numpy batches). */
+int ta_host_alloc(ta_ctx* ctx, size_t bytes, void** out);
+void ta_host_free(ta_ctx* ctx, void* ptr);
+
 /* ---- frames (replaces `torch.as_tensor(images, device=...)`,
  *      retinaface/wrapper.py:144, openpose/wrapper.py:121, arcface/wrapper.py:170) -------- */
 int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, ta_frames** out);

@@ -12,22 +12,70 @@
 
 static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-static void free_plan(ta_model* m) {
-  if (m->arena) (void)hipFree(m->arena);
-  if (m->ktab_dev) (void)hipFree(m->ktab_dev);
-  m->arena = nullptr;
-  m->ktab_dev = nullptr;
-  m->arena_bytes = 0;
+#define TA_MAX_PLANS 4
+#define TA_MAX_PLAN_BYTES ((size_t)96 << 30)
+
+static void destroy_plan(ta_plan* pl) {
+  if (!pl) return;
+  if (pl->arena) (void)hipFree(pl->arena);
+  if (pl->ktab_dev) (void)hipFree(pl->ktab_dev);
+  delete pl;
+}
+
+static void activate(ta_model* m, ta_plan* pl) {
+  m->active = pl;
+  pl->last_use = ++m->use_counter;
+  m->plan_n = pl->n;
+  m->plan_h = pl->h;
+  m->plan_w = pl->w;
+  m->tensors = pl->tensors;
+  m->ktab_dev = pl->ktab_dev;
+  m->ktab_off = pl->ktab_off;
+}
+
+static void free_plans(ta_model* m) {
+  for (ta_plan* pl : m->plans) destroy_plan(pl);
+  m->plans.clear();
+  m->active = nullptr;
   m->plan_n = m->plan_h = m->plan_w = 0;
   m->tensors.clear();
+  m->ktab_dev = nullptr;
 }
 
 int ta_model_plan(ta_model* m, int n, int h, int w) {
   ta_ctx* ctx = m->ctx;
   if (n <= 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "plan: bad input shape %dx%dx%d", n, h, w);
-  if (m->plan_n == n && m->plan_h == h && m->plan_w == w) return TA_OK;
+  if (m->active && m->plan_n == n && m->plan_h == h && m->plan_w == w) {
+    m->active->last_use = ++m->use_counter;
+    return TA_OK;
+  }
+  for (ta_plan* pl : m->plans)
+    if (pl->n == n && pl->h == h && pl->w == w) {
+      activate(m, pl);
+      return TA_OK;
+    }
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  free_plan(m);
+  // evict least-recently-used plans beyond the count / byte budget
+  for (;;) {
+    size_t bytes = 0;
+    for (ta_plan* pl : m->plans) bytes += pl->arena_bytes;
+    if (m->plans.size() < TA_MAX_PLANS && bytes <= TA_MAX_PLAN_BYTES) break;
+    if (m->plans.empty()) break;
+    size_t lru = 0;
+    for (size_t i = 1; i < m->plans.size(); ++i)
+      if (m->plans[i]->last_use < m->plans[lru]->last_use) lru = i;
+    if (m->plans[lru] == m->active) m->active = nullptr;
+    destroy_plan(m->plans[lru]);
+    m->plans.erase(m->plans.begin() + lru);
+  }
+  ta_plan* np = new ta_plan();
+  np->n = n;
+  np->h = h;
+  np->w = w;
+  struct guard_t {
+    ta_plan*& p;
+    ~guard_t() { if (p) destroy_plan(p); }
+  } guard{np};
 
   const int T = m->hdr.n_tensors;
   std::vector<ta_tensor> ts(T);
@@ -101,23 +149,23 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     offs[i] = total;
     total += (bytes + 255) & ~(size_t)255;
   }
-  hipError_t e = hipMalloc((void**)&m->arena, total ? total : 256);
+  hipError_t e = hipMalloc((void**)&np->arena, total ? total : 256);
   if (e != hipSuccess) return ta_fail(ctx, TA_E_DEVICE, "plan: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
-  m->arena_bytes = total;
-  TA_HIP(ctx, hipMemsetAsync(m->arena, 0, total ? total : 256, ctx->stream));
+  np->arena_bytes = total;
+  TA_HIP(ctx, hipMemsetAsync(np->arena, 0, total ? total : 256, ctx->stream));
   for (int i = 0; i < T; ++i)
-    if (set[i] && ts[i].owns) ts[i].dev = (float*)(m->arena + offs[i]);
+    if (set[i] && ts[i].owns) ts[i].dev = (float*)(np->arena + offs[i]);
   for (int i = 0; i < T; ++i)
     if (set[i] && !ts[i].owns) ts[i].dev = ts[m->tdesc[i].alias_of].dev;
 
   // K-offset tables
   std::vector<int32_t> ktab;
-  m->ktab_off.assign(m->ops.size(), 0);
+  np->ktab_off.assign(m->ops.size(), 0);
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     const ta_op_desc& op = m->ops[oi];
     if (op.type != TA_OP_CONV) continue;
     const ta_tensor& ti = ts[op.in];
-    m->ktab_off[oi] = ktab.size();
+    np->ktab_off[oi] = ktab.size();
     const int cpt = op.cin / 4;
     const int nq = op.kh * op.kw * cpt;
     if (nq > op.n_slabs * 8) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu has too few K slabs", oi);
@@ -132,14 +180,15 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     }
   }
   if (!ktab.empty()) {
-    TA_HIP(ctx, hipMalloc((void**)&m->ktab_dev, ktab.size() * sizeof(int32_t)));
-    TA_HIP(ctx, hipMemcpy(m->ktab_dev, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    TA_HIP(ctx, hipMalloc((void**)&np->ktab_dev, ktab.size() * sizeof(int32_t)));
+    TA_HIP(ctx, hipMemcpy(np->ktab_dev, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  m->tensors.swap(ts);
-  m->plan_n = n;
-  m->plan_h = h;
-  m->plan_w = w;
+  np->tensors.swap(ts);
+  ta_plan* done = np;
+  np = nullptr;                 // disarm the guard
+  m->plans.push_back(done);
+  activate(m, done);
   return TA_OK;
 }
 
@@ -305,7 +354,7 @@ void ta_model_free(ta_model* m) {
   ta_enter(m ? m->ctx : nullptr);
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
-  free_plan(m);
+  free_plans(m);
   if (m->weights_dev) (void)hipFree(m->weights_dev);
   delete m;
 }

@@ -296,6 +296,19 @@ static void axis_table(int src, int dst, bool clamp_frac, std::vector<int32_t>& 
 
 extern "C" {
 
+int ta_host_alloc(ta_ctx* ctx, size_t bytes, void** out) {
+  ta_enter(ctx);
+  if (!ctx || !out || bytes == 0) return ta_fail(ctx, TA_E_INVALID, "host_alloc: bad args");
+  *out = nullptr;
+  TA_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return TA_OK;
+}
+
+void ta_host_free(ta_ctx* ctx, void* ptr) {
+  ta_enter(ctx);
+  if (ptr) (void)hipHostFree(ptr);
+}
+
 int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
   ta_enter(ctx);
   if (!ctx || !out || n < 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_alloc: bad shape");

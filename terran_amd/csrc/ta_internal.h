@@ -178,6 +178,17 @@ int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, i
 // ---------------------------------------------------------------------------------------------
 // Model
 // ---------------------------------------------------------------------------------------------
+// One activation plan = everything that depends on the input shape (N, H, W).
+struct ta_plan {
+  int n = 0, h = 0, w = 0;
+  std::vector<ta_tensor> tensors;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int32_t* ktab_dev = nullptr;
+  std::vector<size_t> ktab_off;   // per op, element offset into ktab_dev
+  uint64_t last_use = 0;
+};
+
 struct ta_model {
   ta_ctx* ctx = nullptr;
   int kind = 0;
@@ -185,13 +196,15 @@ struct ta_model {
   std::vector<ta_tensor_desc> tdesc;
   std::vector<ta_op_desc> ops;
   char* weights_dev = nullptr;
-  // current plan
+  // small LRU of plans (lists of differently-sized images alternate between a few shapes); `tensors`,
+  // `ktab_dev`, `ktab_off` mirror the active plan
+  std::vector<ta_plan*> plans;
+  ta_plan* active = nullptr;
+  uint64_t use_counter = 0;
   int plan_n = 0, plan_h = 0, plan_w = 0;
   std::vector<ta_tensor> tensors;
-  char* arena = nullptr;
-  size_t arena_bytes = 0;
   int32_t* ktab_dev = nullptr;
-  std::vector<size_t> ktab_off;   // per op, element offset into ktab_dev
+  std::vector<size_t> ktab_off;
 };
 
 int ta_model_plan(ta_model* m, int n, int h, int w);

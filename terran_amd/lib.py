@@ -38,6 +38,8 @@ SIGNATURES = {
     'ta_profile_read': (c_int, [c_void_p, c_int, f64p, P(C.c_int64), f64p]),
     'ta_timer_start': (c_int, [c_void_p]),
     'ta_timer_stop': (c_int, [c_void_p, f64p]),
+    'ta_host_alloc': (c_int, [c_void_p, c_size_t, P(c_void_p)]),
+    'ta_host_free': (None, [c_void_p, c_void_p]),
     'ta_frames_upload': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, P(c_void_p)]),
     'ta_frames_alloc': (c_int, [c_void_p, c_int, c_int, c_int, P(c_void_p)]),
     'ta_frames_shape': (c_int, [c_void_p, P(c_int), P(c_int), P(c_int)]),
@@ -152,6 +154,19 @@ class Context:
         images = np.ascontiguousarray(images, dtype=np.uint8)
         assert images.ndim == 4 and images.shape[3] == 3
         return Frames(self, images)
+
+    def pinned_array(self, shape):
+        """uint8 numpy array backed by page-locked host memory (freed with `free_pinned`)."""
+        n = int(np.prod(shape))
+        p = c_void_p()
+        self.check(self.lib.ta_host_alloc(self.h, n, C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(shape)
+        arr_ptr = p.value
+        return arr, arr_ptr
+
+    def free_pinned(self, ptr):
+        if getattr(self, 'h', None):
+            self.lib.ta_host_free(self.h, c_void_p(ptr))
 
     def cosine_distance(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -289,3 +289,40 @@ def test_facade_pose_and_recognition_vs_reference(states, precision):
     assert many[1].shape == (0, 512) and str(many[1].dtype) == str(g['many1_dtype'])
     with pytest.raises(ValueError):
         rec([image, image], [[]])
+
+
+# ---- plan cache / video reader --------------------------------------------------------------------
+def test_plan_cache_alternating_shapes(det):
+    """Lists of differently-sized images alternate between shapes: cached plans must give identical results,
+    also after more shapes than the cache holds (LRU eviction + re-plan)."""
+    shapes = [(64, 96), (75, 101), (96, 64), (128, 80), (50, 60), (64, 96), (75, 101)]
+    first = {}
+    for rep in range(2):
+        for i, (h, w) in enumerate(shapes):
+            out = det.call(synth.frames(100 + i % 5, 2, h, w))
+            key = (i % 5, h, w)
+            if key in first:
+                assert [len(x) for x in out] == [len(x) for x in first[key]]
+                for a, b in zip(out, first[key]):
+                    for p, q in zip(a, b):
+                        assert np.array_equal(p['bbox'], q['bbox']) and p['score'] == q['score']
+            else:
+                first[key] = out
+
+
+def test_raw_video_reader_feeds_facade(states, precision):
+    import io
+    from terran_amd import Detection, video
+    frames = synth.frames(11, 5, 96, 128)
+    d = Detection(short_side=64, device=0, state=states('retinaface'), precision=precision)
+    ref = d(frames)
+    got = []
+    with video.RawVideoReader(io.BytesIO(frames.tobytes()), 128, 96, batch_size=2, device=0) as reader:
+        for batch in reader:                      # lib.Frames, already in HBM
+            assert batch.shape[1:] == (96, 128, 3)
+            got += d(batch)
+            batch.free()
+    assert [len(x) for x in got] == [len(x) for x in ref]
+    for a, b in zip(got, ref):
+        for p, q in zip(a, b):
+            assert np.array_equal(p['bbox'], q['bbox']) and np.array_equal(p['landmarks'], q['landmarks'])

@@ -150,3 +150,33 @@ def test_sharded_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'SHARD_OK' in outs[0]
+
+
+def test_raw_video_reader_framing():
+    """Batch framing of the rawvideo rgb24 contract (terran/io/video/reader.py:88-117), no GPU: whole batches,
+    a short final batch, trailing partial frame dropped, end of stream, prefetch thread shutdown."""
+    import io
+    from terran_amd import video
+    w, h, bs = 8, 6, 4
+    frames = np.random.default_rng(0).integers(0, 256, (10, h, w, 3), dtype=np.uint8)
+    raw = frames.tobytes() + b'\x01\x02\x03'                      # 10 frames + 3 stray bytes
+    got = list(video.RawVideoReader(io.BytesIO(raw), w, h, batch_size=bs, upload=lambda a: a.copy()))
+    assert [g.shape[0] for g in got] == [4, 4, 2]
+    assert np.array_equal(np.concatenate(got), frames)
+    r = video.RawVideoReader(io.BytesIO(frames[:4].tobytes()), w, h, batch_size=bs, upload=lambda a: a.copy())
+    assert r.read().shape == (4, h, w, 3)
+    with pytest.raises(video.EndOfVideo):
+        r.read()
+    with pytest.raises(video.VideoClosed):
+        next(r)
+    assert list(video.RawVideoReader(io.BytesIO(b''), w, h, batch_size=bs, upload=lambda a: a)) == []
+
+    class Boom(io.RawIOBase):
+        def readinto(self, b):
+            raise OSError('pipe broke')
+    with pytest.raises(OSError):
+        list(video.RawVideoReader(Boom(), w, h, batch_size=bs, upload=lambda a: a))
+    with video.RawVideoReader(io.BytesIO(frames.tobytes() * 50), w, h, batch_size=bs, upload=lambda a: a.copy()) as rr:
+        next(rr)                                                   # close mid-stream: the worker must stop
+    rr._thread.join(timeout=5)
+    assert not rr._thread.is_alive()
