@@ -39,7 +39,7 @@ class ArcFace:
         self.precision = runtime.resolve_precision(precision)
         self.image_side = image_side
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
-        self.model = lib.Model(self.ctx, pack.pack_arcface(runtime.resolve_state('arcface', state), runtime.resolve_precision(precision)))
+        self.model = lib.Model(self.ctx, runtime.packed_program('arcface', state, self.precision))
 
     # -- device entry points ---------------------------------------------------------------
     def embed_crops(self, crops, normalize=True):

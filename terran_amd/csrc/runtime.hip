@@ -309,8 +309,14 @@ void ta_host_free(ta_ctx* ctx, void* ptr) {
   if (ptr) (void)hipHostFree(ptr);
 }
 
+static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames** out);
+
 int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
   ta_enter(ctx);
+  return frames_alloc(ctx, n, h, w, true, out);
+}
+
+static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames** out) {
   if (!ctx || !out || n < 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_alloc: bad shape");
   ta_frames* f = new ta_frames{ctx, n, h, w, nullptr};
   size_t bytes = (size_t)n * h * w * 3;
@@ -320,14 +326,14 @@ int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
     delete f;
     return ta_fail(ctx, TA_E_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   }
-  TA_HIP(ctx, hipMemsetAsync(f->dev, 0, bytes, ctx->stream));
+  if (zero) TA_HIP(ctx, hipMemsetAsync(f->dev, 0, bytes, ctx->stream));   // only pad-merge canvases need zeros
   *out = f;
   return TA_OK;
 }
 
 int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, ta_frames** out) {
   if (!nhwc_rgb && n > 0) return ta_fail(ctx, TA_E_INVALID, "frames_upload: null data");
-  TA_TRY(ta_frames_alloc(ctx, n, h, w, out));
+  TA_TRY(frames_alloc(ctx, n, h, w, false, out));
   const size_t bytes = (size_t)n * h * w * 3;
   if (bytes) {
     TA_HIP(ctx, hipMemcpyAsync((*out)->dev, nhwc_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -367,7 +373,7 @@ void ta_frames_free(ta_frames* f) {
 int ta_frames_resize(ta_ctx* ctx, const ta_frames* src, int dst_h, int dst_w, ta_frames** out) {
   ta_enter(ctx);
   if (!ctx || !src || !out || dst_h <= 0 || dst_w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_resize: bad args");
-  TA_TRY(ta_frames_alloc(ctx, src->n, dst_h, dst_w, out));
+  TA_TRY(frames_alloc(ctx, src->n, dst_h, dst_w, false, out));
   std::vector<int32_t> xt, yt;
   axis_table(src->w, dst_w, true, xt);
   axis_table(src->h, dst_h, false, yt);
@@ -462,12 +468,12 @@ int ta_frames_resize_bicubic(ta_ctx* ctx, const ta_frames* src, int dst_h, int d
   const uint8_t* cur = src->dev;
   int cw = src->w;
   if (dst_w != src->w) {
-    TA_TRY(ta_frames_alloc(ctx, src->n, src->h, dst_w, &tmp));
+    TA_TRY(frames_alloc(ctx, src->n, src->h, dst_w, false, &tmp));
     TA_TRY(pil_pass(ctx, cur, src->n, src->h, src->w, tmp->dev, dst_w, 0));
     cur = tmp->dev;
     cw = dst_w;
   }
-  int rc = ta_frames_alloc(ctx, src->n, dst_h, dst_w, out);
+  int rc = frames_alloc(ctx, src->n, dst_h, dst_w, false, out);
   if (rc == TA_OK) {
     if (dst_h != src->h) {
       rc = pil_pass(ctx, cur, src->n, src->h, cw, (*out)->dev, dst_h, 1);

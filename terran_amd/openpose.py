@@ -36,7 +36,7 @@ class OpenPose:
         self.precision = runtime.resolve_precision(precision)
         self.short_side = short_side
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
-        self.model = lib.Model(self.ctx, pack.pack_openpose(runtime.resolve_state('openpose', state), runtime.resolve_precision(precision)))
+        self.model = lib.Model(self.ctx, runtime.packed_program('openpose', state, self.precision))
 
     def call_frames(self, frames):
         """frames: lib.Frames at ORIGINAL resolution; resized on the device to `short_side`."""

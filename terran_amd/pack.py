@@ -156,7 +156,36 @@ class Program:
         op['in'] = tin
         self.ops.append(op)
 
+    @classmethod
+    def from_cache(cls, path):
+        """Load a program written by `save_cache` (packed blob + debug-tap names)."""
+        import json
+        with open(path, 'rb') as f:
+            head = f.read(16)
+            if head[:8] != b'TAMCACHE':
+                raise ValueError('not a pack cache file')
+            n = int.from_bytes(head[8:16], 'little')
+            meta = json.loads(f.read(n).decode())
+            blob = f.read()
+        self = cls(meta['kind'], meta['precision'])
+        self.names = {k: tuple(v) for k, v in meta['names'].items()}
+        self.outputs = meta['outputs']
+        self._blob = blob
+        return self
+
+    def save_cache(self, path):
+        import json
+        import os
+        meta = json.dumps({'kind': self.kind, 'precision': self.precision, 'names': self.names,
+                           'outputs': [int(o) for o in self.outputs]}).encode()
+        tmp = path + '.tmp.%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(b'TAMCACHE' + len(meta).to_bytes(8, 'little') + meta + self.blob())
+        os.replace(tmp, path)                      # atomic: concurrent ranks may race to write the same file
+
     def blob(self):
+        if getattr(self, '_blob', None) is not None:
+            return self._blob
         hdr = np.zeros(1, HEADER_DT)
         tens = np.zeros(len(self.tensors), TENSOR_DT)
         for i, (c, h, a) in enumerate(self.tensors):

@@ -13,7 +13,7 @@ class RetinaFace:
         self.precision = runtime.resolve_precision(precision)
         self.nms_threshold = nms_threshold
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
-        self.model = lib.Model(self.ctx, pack.pack_retinaface(runtime.resolve_state('retinaface', state), runtime.resolve_precision(precision)))
+        self.model = lib.Model(self.ctx, runtime.packed_program('retinaface', state, self.precision))
 
     def detect_arrays(self, frames, threshold=0.5):
         """-> (counts (N,) int32, boxes (T,4), landmarks (T,5,2), scores (T,)) float32, images concatenated."""

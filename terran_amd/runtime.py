@@ -60,3 +60,32 @@ def resolve_precision(precision=None):
     if p not in ('f32', 'bf16x3', 'bf16'):
         raise ValueError('unknown precision %r' % (p,))
     return p
+
+
+def packed_program(kind, state, precision):
+    """Pack `state` for `kind`, going through the repack cache when the weights come from a checkpoint file.
+
+    Cache key = checkpoint id + precision + size/mtime of the .pth (terran/checkpoint.py:118-150 layout):
+    `$TERRAN_HOME/checkpoints/<id>.<precision>.tam`.  Dict states (tests, bench) are packed directly."""
+    from . import checkpoint, pack
+    packer = getattr(pack, 'pack_%s' % kind)
+    path = None
+    if state is None:
+        path = checkpoint.find_checkpoint_file(kind)
+    elif isinstance(state, (str, os.PathLike)):
+        path = state
+    if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE'):
+        return packer(resolve_state(kind, state), precision)
+    st = os.stat(path)
+    cache = '%s.%s.%d.%d.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime))
+    if os.path.exists(cache):
+        try:
+            return pack.Program.from_cache(cache)
+        except Exception:
+            pass                                    # unreadable cache: repack below
+    prog = packer(weights.load_state(path), precision)
+    try:
+        prog.save_cache(cache)
+    except OSError:
+        pass                                        # read-only checkpoint dir: run uncached
+    return prog

@@ -326,3 +326,55 @@ def test_raw_video_reader_feeds_facade(states, precision):
     for a, b in zip(got, ref):
         for p, q in zip(a, b):
             assert np.array_equal(p['bbox'], q['bbox']) and np.array_equal(p['landmarks'], q['landmarks'])
+
+
+# ---- limits, error paths, argument handling ---------------------------------------------------------
+def test_retinaface_many_candidates_global_sort_and_thresholds(ctx):
+    """More candidates than the LDS sort holds (8192) take the global-memory bitonic path; custom thresholds."""
+    from oracle import retinaface_post
+    from terran_amd import retinaface
+    rng = np.random.default_rng(9)
+    H, W, N = 640, 640, 1
+    heads = []
+    for s in (32, 16, 8):
+        fh, fw = -(-H // s), -(-W // s)
+        prob = rng.uniform(0.3, 1.0, (N, 4, fh, fw)).astype(np.float32)          # ~70 % of 16800 anchors pass 0.5
+        bbox = rng.normal(0, 0.3, (N, 8, fh, fw)).astype(np.float32)
+        bbox[:, [2, 3, 6, 7]] = 0.0
+        heads += [prob, bbox, rng.normal(0, 0.3, (N, 20, fh, fw)).astype(np.float32)]
+    for thr, nms in ((0.5, 0.4), (0.9, 0.1), (0.3, 0.7)):
+        ref = retinaface_post.postprocess(heads, H, W, thr, nms)
+        got = retinaface.postprocess(ctx, heads, H, W, thr, nms)
+        assert [len(g) for g in got] == [len(r) for r in ref] and len(ref[0]) > 50
+        for a, b in zip(got[0], ref[0]):
+            assert np.array_equal(a['bbox'], b['bbox']) and a['score'] == b['score']
+
+
+def test_openpose_overflow_is_an_error_not_a_hang(ctx):
+    """A flat heat-map makes every interior pixel a peak (>= against equal neighbours): the per-part limit must
+    surface as TA_E_OVERFLOW, never as truncation or a hang."""
+    from terran_amd import lib, openpose
+    hm = np.full((1, 19, 12, 16), 0.5, np.float32)
+    paf = np.zeros((1, 38, 12, 16), np.float32)
+    with pytest.raises(lib.TerranAmdError) as e:
+        openpose.group(ctx, paf, hm, 1.0)
+    assert e.value.code == lib.E_OVERFLOW
+    # and the context is still usable afterwards
+    g = openpose.group(ctx, np.zeros((1, 38, 6, 8), np.float32), np.zeros((1, 19, 6, 8), np.float32), 1.0)
+    assert g == [[]]
+
+
+def test_argument_and_shape_errors(det, arc, ctx):
+    from terran_amd import lib
+    assert len(det.call(np.zeros((1, 8, 8, 3), np.uint8))) == 1    # tiny frames: 1x1 maps at every stride (ceil)
+    out = det.call(np.ascontiguousarray(synth.frames(1, 2, 64, 96)[:, ::-1]))      # flipped view made contiguous
+    assert len(out) == 2
+    flipped = synth.frames(1, 2, 64, 96)[:, :, ::-1]                               # NON-contiguous input
+    assert [len(x) for x in det.call(flipped)] == [len(x) for x in det.call(np.ascontiguousarray(flipped))]
+    with pytest.raises(ValueError):
+        from terran_amd import ArcFace
+        ArcFace(device=0, image_side=96, state={})
+    with pytest.raises(ValueError):
+        from terran_amd import RetinaFace
+        RetinaFace(device='cpu', state={})
+    assert arc.call([], []) == []

@@ -180,3 +180,25 @@ def test_raw_video_reader_framing():
         next(rr)                                                   # close mid-stream: the worker must stop
     rr._thread.join(timeout=5)
     assert not rr._thread.is_alive()
+
+
+def test_pack_cache_roundtrip(tmp_path, states, monkeypatch):
+    """Checkpoint file -> packed program -> cache file -> identical blob (the registry/CLI integration row)."""
+    import torch
+    from terran_amd import runtime, pack, checkpoint
+    monkeypatch.setenv('TERRAN_HOME', str(tmp_path))
+    (tmp_path / 'checkpoints').mkdir()
+    sd = states('retinaface')
+    pth = tmp_path / 'checkpoints' / 'b5d77fff.pth'               # the reference's id for RetinaFace
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, pth)
+    assert checkpoint.find_checkpoint_file('retinaface') == pth
+    p1 = runtime.packed_program('retinaface', None, 'bf16x3')
+    cached = list((tmp_path / 'checkpoints').glob('*.tam'))
+    assert len(cached) == 1
+    p2 = runtime.packed_program('retinaface', None, 'bf16x3')     # served from the cache
+    assert p2.blob() == p1.blob() and p2.names == p1.names and p2.kind == pack.MODEL_RETINAFACE
+    assert p1.blob() == pack.pack_retinaface(sd, 'bf16x3').blob()
+    p3 = runtime.packed_program('retinaface', None, 'f32')        # other precision: its own cache entry
+    assert p3.blob() != p1.blob() and len(list((tmp_path / 'checkpoints').glob('*.tam'))) == 2
+    with pytest.raises(ValueError):
+        runtime.resolve_state('openpose', None)                   # no file, no synthetic fallback
