@@ -22,6 +22,7 @@
 //   PReLU / residual (optionally nearest-x2 upsampled) / second affine output.
 #include <stdlib.h>
 
+#include "act_format.h"
 #include "ta_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -105,7 +106,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = co_base + a * 32 + 8 * j;
-          r4[a][j] = *(const f32x4*)(rs + (co < co_max ? co : co_max));   // clamped: masked at the store
+          r4[a][j] = ta_ld4(rs, p.res_ch + (co < co_max ? co : co_max), p.res_fmt);   // clamped: masked at the store
         }
 #pragma unroll
       for (int a = 0; a < WM_TILES; ++a)
@@ -121,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = co_base + a * 32 + 8 * j;
-          if (co < p.cout) *(f32x4*)(o + co) = v[a][j];
+          if (co < p.cout) ta_st4(o, p.out_ch + co, p.out_fmt, v[a][j]);
         }
     }
     if (p.out2) {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
-            if (co < p.cout) *(f32x4*)(o2 + co) = z;
+            if (co < p.cout) ta_st4(o2, p.o2_ch + co, p.o2_fmt, z);
           }
       }
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
 //  * STAGES LDS buffers, raw s_barrier and a COUNTED s_waitcnt vmcnt(N): STAGES-1 slabs stay in flight
 //    across the barrier, which is what hides the L2/HBM latency once the MFMA work per slab shrinks
 //    (bf16x3 / bf16: 768 / 256 MFMA cycles per slab instead of 4096).
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES>
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES, bool BSPLIT>
 __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_TILES) * 32 * 128 <= 80 * 1024) ? 2 : 1) void conv_igemm_pipe(const ta_conv_launch p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
   constexpr int BM = WAVES_N * WN_TILES * 32;
@@ -459,14 +460,19 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
         }
 #pragma unroll
         for (int b = 0; b < WN_TILES; ++b) {
-          f.b32[b][2 * t] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
-          f.b32[b][2 * t + 1] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
+          if constexpr (BSPLIT) {      // pre-split activations: same [hi | lo] row image as the weights
+            f.bh[b][t] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+            if constexpr (PREC == PREC_BF16X3) f.bl[b][t] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+          } else {
+            f.b32[b][2 * t] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
+            f.b32[b][2 * t + 1] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
+          }
         }
       }
     }
   };
   auto convert = [&](Frag& f) {
-    if constexpr (PREC != PREC_F32) {
+    if constexpr (PREC != PREC_F32 && !BSPLIT) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     load_raw(nxt, lds + nxt_stage * STAGE);
     mma(cur);
     convert(nxt);
-    if constexpr (PREC != PREC_F32) {
+    if constexpr (PREC != PREC_F32 && !BSPLIT) {
       // hipcc otherwise emits the MFMAs back to back and the hi/lo split after them: pin an interleave
       // (all fragment reads first, then 1 MFMA : VPM VALU) so the split runs in the MFMA shadows.
       constexpr int NREAD = 2 * (WM_TILES * (PREC == PREC_BF16X3 ? 2 : 1) + 2 * WN_TILES);
@@ -604,7 +610,7 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   return TA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES>
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, int STAGES, bool BSPLIT>
 static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
   constexpr int BM = WAVES_N * WN_TILES * 32;
@@ -612,7 +618,7 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
-  auto kern = conv_igemm_pipe<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES>;
+  auto kern = conv_igemm_pipe<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES, BSPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -628,9 +634,14 @@ static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
   // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles)
   static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
   if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
-    if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3>(ctx, p);
-    if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3>(ctx, p);
+    if constexpr (PREC != PREC_F32) {
+      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
+    }
+    if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
+    if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
+    if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
   }
+  if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
   if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2, PREC>(ctx, p);
   if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
   return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);

@@ -1,6 +1,7 @@
 // HBM-bound layer kernels (NHWC float32, 16-byte vector accesses, channel-fastest threads):
 // depthwise 3x3 (+folded BN bias, ReLU), 2x2 max-pool, channel-slice copy, and the uint8 ->
 // float pre-processing of the three wrappers.
+#include "act_format.h"
 #include "ta_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,13 +19,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const ta_dw_launch p) {
     const int y = (int)(pix % p.Ho);
     const int img = (int)(pix / p.Ho);
     const float* src = p.in + (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row +
-                       (size_t)(x * p.stride) * p.in_pix + p.in_off0 + cg * 4;
+                       (size_t)(x * p.stride) * p.in_pix + p.in_off0;
     f32x4 acc = *(const f32x4*)(p.bias + cg * 4);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const f32x4 v = *(const f32x4*)(src + (size_t)ky * p.in_row + (size_t)kx * p.in_pix);
+        const f32x4 v = ta_ld4(src + (size_t)ky * p.in_row + (size_t)kx * p.in_pix, cg * 4, p.in_fmt);
         const f32x4 w = *(const f32x4*)(p.w + (ky * 3 + kx) * p.C + cg * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v[e], w[e], acc[e]);
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const ta_dw_launch p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
     }
-    *(f32x4*)(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0 +
-              cg * 4) = acc;
+    ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, cg * 4,
+           p.out_fmt, acc);
   }
 }
 
@@ -55,7 +56,7 @@ int ta_launch_dwconv(ta_ctx* ctx, const ta_dw_launch& p) {
 }
 
 // ---- 2x2/2 max-pool, floor (openpose/model.py:8-13) ----------------------------------------
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float* in, float* out, int N, int Ho, int Wo, int C,
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* in, float* out, int in_fmt, int out_fmt, int N, int Ho, int Wo, int C,
                                                         int in_img, int in_row, int in_pix, int in_off0,
                                                         int out_img, int out_row, int out_pix, int out_off0) {
   const int c4 = C >> 2;
@@ -68,13 +69,13 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* in, float* o
     pix /= Wo;
     const int y = (int)(pix % Ho);
     const int img = (int)(pix / Ho);
-    const float* s = in + (size_t)img * in_img + (size_t)(2 * y) * in_row + (size_t)(2 * x) * in_pix + in_off0 + cg * 4;
-    const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + in_pix);
-    const f32x4 c = *(const f32x4*)(s + in_row), d = *(const f32x4*)(s + in_row + in_pix);
+    const float* s = in + (size_t)img * in_img + (size_t)(2 * y) * in_row + (size_t)(2 * x) * in_pix + in_off0;
+    const f32x4 a = ta_ld4(s, cg * 4, in_fmt), b = ta_ld4(s + in_pix, cg * 4, in_fmt);
+    const f32x4 c = ta_ld4(s + in_row, cg * 4, in_fmt), d = ta_ld4(s + in_row + in_pix, cg * 4, in_fmt);
     f32x4 m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-    *(f32x4*)(out + (size_t)img * out_img + (size_t)y * out_row + (size_t)x * out_pix + out_off0 + cg * 4) = m;
+    ta_st4(out + (size_t)img * out_img + (size_t)y * out_row + (size_t)x * out_pix + out_off0, cg * 4, out_fmt, m);
   }
 }
 
@@ -82,7 +83,7 @@ int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out) {
   const size_t total = (size_t)out.n * out.h * out.w * (out.c / 4);
   if (!total) return TA_OK;
   ta_prof_scope scope(ctx, 1, (double)total * 16 * 5);
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, out.n, out.h,
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, in.fmt, out.fmt, out.n, out.h,
                      out.w, out.c, (int)((size_t)in.hp() * in.wp() * in.c), in.wp() * in.c, in.c,
                      (int)in.off(0, 0, 0), (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c, out.c,
                      (int)out.off(0, 0, 0));
@@ -110,6 +111,9 @@ __global__ __launch_bounds__(256) void copych_kernel(const float* in, float* out
 }
 
 int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch) {
+  // raw 16-byte copies: with pre-split tensors the slice must be whole 32-channel blocks in the same format
+  if (in.fmt != out.fmt || (in.fmt == TA_FMT_SPLIT && ((in_ch | out_ch | ch) & 31)))
+    return ta_fail(ctx, TA_E_INVALID, "copych: incompatible tensor formats");
   const size_t total = (size_t)in.n * in.h * in.w * (ch / 4);
   if (!total) return TA_OK;
   ta_prof_scope scope(ctx, 1, (double)total * 16 * 2);

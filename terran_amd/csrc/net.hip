@@ -8,6 +8,7 @@
 // the context's stream.
 #include <string.h>
 
+#include "act_format.h"
 #include "ta_internal.h"
 
 static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
@@ -83,6 +84,7 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
   for (int i = 0; i < T; ++i) {
     ts[i].c = m->tdesc[i].channels;
     ts[i].halo = m->tdesc[i].halo;
+    ts[i].fmt = m->tdesc[i].fmt;
     ts[i].n = n;
   }
   const int in_id = m->hdr.input_tensor;
@@ -138,6 +140,8 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     }
   }
   for (int i = 0; i < T; ++i) TA_TRY(resolve_alias(i));
+  for (int i = 0; i < T; ++i)
+    if (ts[i].fmt == TA_FMT_SPLIT && ts[i].c % 32) return ta_fail(ctx, TA_E_INVALID, "plan: pre-split tensor %d has %d channels", i, ts[i].c);
 
   // carve the arena
   size_t total = 0;
@@ -232,14 +236,19 @@ int ta_model_run_ops(ta_model* m) {
         p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
         p.out_row = to.wp() * to.c;
         p.out_pix = to.c;
-        p.out_off0 = (int)to.off(0, 0, 0) + op.out_ch_off;
+        p.out_off0 = (int)to.off(0, 0, 0);
+        p.out_ch = op.out_ch_off;
+        p.out_fmt = to.fmt;
+        p.in_fmt = ti.fmt;
         if (op.res >= 0) {
           const ta_tensor& tr = m->tensors[op.res];
           p.res = tr.dev;
           p.res_img = (int)((size_t)tr.hp() * tr.wp() * tr.c);
           p.res_row = tr.wp() * tr.c;
           p.res_pix = tr.c;
-          p.res_off0 = (int)tr.off(0, 0, 0) + op.res_ch_off;
+          p.res_off0 = (int)tr.off(0, 0, 0);
+          p.res_ch = op.res_ch_off;
+          p.res_fmt = tr.fmt;
           p.res_up2 = op.res_up2;
         }
         if (op.out2 >= 0) {
@@ -250,7 +259,9 @@ int ta_model_run_ops(ta_model* m) {
           p.o2_img = (int)((size_t)t2.hp() * t2.wp() * t2.c);
           p.o2_row = t2.wp() * t2.c;
           p.o2_pix = t2.c;
-          p.o2_off0 = (int)t2.off(0, 0, 0) + op.out2_ch_off;
+          p.o2_off0 = (int)t2.off(0, 0, 0);
+          p.o2_ch = op.out2_ch_off;
+          p.o2_fmt = t2.fmt;
         }
         TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
         break;
@@ -271,11 +282,14 @@ int ta_model_run_ops(ta_model* m) {
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;
         p.in_pix = ti.c;
-        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.c) + op.in_ch_off;
+        if (op.in_ch_off || op.out_ch_off) return ta_fail(ctx, TA_E_INVALID, "depthwise conv on a channel slice is not supported");
+        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.c);
+        p.in_fmt = ti.fmt;
         p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
         p.out_row = to.wp() * to.c;
         p.out_pix = to.c;
-        p.out_off0 = (int)to.off(0, 0, 0) + op.out_ch_off;
+        p.out_off0 = (int)to.off(0, 0, 0);
+        p.out_fmt = to.fmt;
         TA_TRY(ta_launch_dwconv(ctx, p));
         break;
       }
@@ -414,7 +428,24 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
     for (int c = 0; c < ch; ++c)
       for (int y = 0; y < t.h; ++y)
         for (int x = 0; x < t.w; ++x)
-          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = host[t.off(i, y, x) + ch_off + c];
+        {
+          const int cc = ch_off + c;
+          float v;
+          if (t.fmt == TA_FMT_SPLIT) {
+            const char* b = (const char*)&host[t.off(i, y, x)] + ((cc >> 5) << 7) + ((cc & 31) << 1);
+            uint16_t h16, l16;
+            memcpy(&h16, b, 2);
+            memcpy(&l16, b + 64, 2);
+            const uint32_t hb = (uint32_t)h16 << 16, lb = (uint32_t)l16 << 16;
+            float hf, lf;
+            memcpy(&hf, &hb, 4);
+            memcpy(&lf, &lb, 4);
+            v = hf + lf;
+          } else {
+            v = host[t.off(i, y, x) + cc];
+          }
+          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = v;
+        }
   return TA_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <string.h>
 
+#include "act_format.h"
 #include "ta_internal.h"
 
 #define OP_MAXP 1024       // peaks per (image, part)
@@ -29,9 +30,11 @@ __constant__ int c_limbseq[19][2] = {{2, 3}, {2, 6}, {3, 4}, {4, 5}, {6, 7}, {7,
                                       {12, 13}, {13, 14}, {2, 1}, {1, 15}, {15, 17}, {1, 16}, {16, 18}, {3, 17}, {6, 18}};
 
 struct op_maps {
-  const float* base;      // network-resolution maps, NHWC-like addressing
+  const float* base;      // network-resolution maps, NHWC addressing
   int img, row, pix;      // element strides
-  int paf_off, hm_off;    // element offset of PAF channel 0 / heat-map channel 0 (incl. halo offset)
+  int off0;               // element offset of interior pixel (0,0), channel 0
+  int paf_ch, hm_ch;      // first PAF / heat-map channel
+  int fmt;                // TA_FMT_F32 or TA_FMT_SPLIT (act_format.h)
   int h, w;
 };
 
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, fl
     r /= H8;
     const int c = (int)(r % 57);
     const int img = (int)(r / 57);
-    const float* src = m.base + (size_t)img * m.img + (c < 38 ? m.paf_off + c : m.hm_off + (c - 38));
+    const float* src = m.base + (size_t)img * m.img + m.off0;
+    const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
     const int4 xi = *(const int4*)(xtab + 4 * x);
     const float4 xw = *(const float4*)(xwt + 4 * x);
     const int4 yi = *(const int4*)(ytab + 4 * y);
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, fl
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float* rp = src + (size_t)ys[k] * m.row;
-      const float v0 = rp[(size_t)xi.x * m.pix], v1 = rp[(size_t)xi.y * m.pix];
-      const float v2 = rp[(size_t)xi.z * m.pix], v3 = rp[(size_t)xi.w * m.pix];
+      const float v0 = ta_ld1(rp + (size_t)xi.x * m.pix, ch, m.fmt), v1 = ta_ld1(rp + (size_t)xi.y * m.pix, ch, m.fmt);
+      const float v2 = ta_ld1(rp + (size_t)xi.z * m.pix, ch, m.fmt), v3 = ta_ld1(rp + (size_t)xi.w * m.pix, ch, m.fmt);
       float a = v1 * xw.y;
       a = __builtin_fmaf(v0, xw.x, a);
       a = __builtin_fmaf(v2, xw.z, a);
@@ -589,8 +593,10 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
   mp.img = (int)((size_t)X.hp() * X.wp() * X.c);
   mp.row = X.wp() * X.c;
   mp.pix = X.c;
-  mp.paf_off = (int)X.off(0, 0, 0) + 128;
-  mp.hm_off = (int)X.off(0, 0, 0) + 168;
+  mp.off0 = (int)X.off(0, 0, 0);
+  mp.paf_ch = 128;
+  mp.hm_ch = 168;
+  mp.fmt = X.fmt;
   mp.h = X.h;
   mp.w = X.w;
   return op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required, nullptr);
@@ -614,8 +620,10 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
   mp.img = h * w * c;
   mp.row = w * c;
   mp.pix = c;
-  mp.paf_off = 0;
-  mp.hm_off = 38;
+  mp.off0 = 0;
+  mp.paf_ch = 0;
+  mp.hm_ch = 38;
+  mp.fmt = TA_FMT_F32;
   mp.h = h;
   mp.w = w;
   const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required, nullptr);
@@ -650,8 +658,10 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
     mp.img = h * w * ct;
     mp.row = w * ct;
     mp.pix = ct;
-    mp.paf_off = 0;
-    mp.hm_off = 38;
+    mp.off0 = 0;
+    mp.paf_ch = 0;
+    mp.hm_ch = 38;
+    mp.fmt = TA_FMT_F32;
     mp.h = h;
     mp.w = w;
     std::vector<float> up((size_t)n * 57 * 64 * h * w);

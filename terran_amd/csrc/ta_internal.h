@@ -34,7 +34,7 @@ struct ta_tensor_desc {
   int32_t channels;   // C_total (multiple of 4)
   int32_t halo;
   int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0)
-  int32_t reserved;
+  int32_t fmt;        // TA_FMT_F32 / TA_FMT_SPLIT (act_format.h)
 };
 
 struct ta_op_desc {
@@ -126,7 +126,7 @@ struct ta_frames {
 // ---------------------------------------------------------------------------------------------
 struct ta_tensor {
   float* dev = nullptr;   // base of the padded allocation
-  int n = 0, h = 0, w = 0, c = 0, halo = 0;
+  int n = 0, h = 0, w = 0, c = 0, halo = 0, fmt = 0;
   bool owns = true;
   int hp() const { return h + 2 * halo; }
   int wp() const { return w + 2 * halo; }
@@ -149,11 +149,12 @@ struct ta_conv_launch {
   int M, Ho, Wo, n_slabs, coutp, cout, act, stride, prec;
   int uniform_k, k_cblocks, k_w, k_h, in_ch_off;
   int Wq;                                      // pixel decomposition width (== Wo except in the row-run kernel)   // cin % 32 == 0: slabs walk (channel block, kx, ky) without a table
-  // element strides / offsets
+  // element strides / pixel offsets (channel offsets are separate: the split format is not linear in the channel)
   int in_img, in_row, in_pix, in_off0;
-  int out_img, out_row, out_pix, out_off0;
-  int res_img, res_row, res_pix, res_off0, res_up2;
-  int o2_img, o2_row, o2_pix, o2_off0;
+  int out_img, out_row, out_pix, out_off0, out_ch, out_fmt;
+  int res_img, res_row, res_pix, res_off0, res_up2, res_ch, res_fmt;
+  int o2_img, o2_row, o2_pix, o2_off0, o2_ch, o2_fmt;
+  int in_fmt;
 };
 
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);
@@ -164,8 +165,8 @@ struct ta_dw_launch {
   const float* bias;   // [C]
   float* out;
   int N, Ho, Wo, C, stride, relu;
-  int in_img, in_row, in_pix, in_off0;
-  int out_img, out_row, out_pix, out_off0;
+  int in_img, in_row, in_pix, in_off0, in_fmt;
+  int out_img, out_row, out_pix, out_off0, out_fmt;
 };
 int ta_launch_dwconv(ta_ctx* ctx, const ta_dw_launch& p);
 int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out);

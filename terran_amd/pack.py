@@ -28,7 +28,8 @@ HEADER_DT = np.dtype({
     'offsets': [0, 4, 8, 12, 16, 20, 24, 28, 96, 104, 112, 120],
     'itemsize': 128,
 })
-TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('reserved', '<i4')])
+TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
+FMT_F32, FMT_SPLIT = 0, 1
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
            'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
@@ -76,11 +77,16 @@ class Program:
         self.names = {}        # debug taps: name -> (tensor, ch_off, ch)
         self.input_tensor = None
         self.outputs = []
+        self.f32_only = set()
+        self.allow_split = True
 
-    def tensor(self, channels, halo, alias_of=-1, name=None):
+    def tensor(self, channels, halo, alias_of=-1, name=None, f32=False):
+        """f32=True pins the tensor to plain float32 (outputs read by post-processing kernels / the host)."""
         assert channels % 4 == 0
         self.tensors.append((channels, halo, alias_of))
         tid = len(self.tensors) - 1
+        if f32:
+            self.f32_only.add(tid)
         if name:
             self.names[name] = (tid, 0, channels)
         return tid
@@ -183,13 +189,46 @@ class Program:
             f.write(b'TAMCACHE' + len(meta).to_bytes(8, 'little') + meta + self.blob())
         os.replace(tmp, path)                      # atomic: concurrent ranks may race to write the same file
 
+    def tensor_formats(self):
+        """Storage format per tensor.  In the bf16 modes a tensor is kept PRE-SPLIT -- per pixel and 32-channel
+        block, 32 bf16 `hi` then 32 bf16 `lo` (x = hi + lo; same 4 bytes per element as float32) -- when all of its
+        conv consumers are whole-block reads by the pipelined kernel, whose MFMA operand fragments then come
+        straight out of LDS with no conversion VALU.  Everything else stays float32."""
+        n = len(self.tensors)
+        fmt = [FMT_SPLIT if (self.prec != 0 and self.allow_split and c % 32 == 0) else FMT_F32
+               for c, _, _ in self.tensors]
+        for t in self.f32_only | {self.input_tensor}:
+            fmt[t] = FMT_F32
+        for op in self.ops:
+            if op['type'] == OP_CONV:
+                pipe = (op['cin'] % 32 == 0 and op['in_ch_off'] % 32 == 0 and op['coutp'] % 64 == 0
+                        and op['n_slabs'] >= 2 and op['n_slabs'] == op['kh'] * op['kw'] * (op['cin'] // 32))
+                if not pipe:
+                    fmt[op['in']] = FMT_F32
+            elif op['type'] == OP_COPYCH:
+                if op['cin'] % 32 or op['in_ch_off'] % 32 or op['out_ch_off'] % 32:
+                    fmt[op['in']] = fmt[op['out']] = FMT_F32
+        changed = True
+        while changed:                                  # aliases share memory; copies are raw
+            changed = False
+            for t, (_, _, a) in enumerate(self.tensors):
+                if a >= 0 and fmt[t] != fmt[a]:
+                    fmt[t] = fmt[a] = FMT_F32
+                    changed = True
+            for op in self.ops:
+                if op['type'] == OP_COPYCH and fmt[op['in']] != fmt[op['out']]:
+                    fmt[op['in']] = fmt[op['out']] = FMT_F32
+                    changed = True
+        return fmt
+
     def blob(self):
         if getattr(self, '_blob', None) is not None:
             return self._blob
         hdr = np.zeros(1, HEADER_DT)
         tens = np.zeros(len(self.tensors), TENSOR_DT)
+        fmts = self.tensor_formats()
         for i, (c, h, a) in enumerate(self.tensors):
-            tens[i] = (c, h, a, 0)
+            tens[i] = (c, h, a, fmts[i])
         ops = np.zeros(len(self.ops), OP_DT)
         for i, op in enumerate(self.ops):
             for k, v in op.items():
@@ -341,7 +380,7 @@ def pack_arcface(sd, precision='f32'):
     bl = np.asarray(sd['final_layer.3.bias'], np.float64) * s + sh
     f = np.arange(7 * 7 * 512)
     ch_pos = (f % 49) * 512 + f // 49
-    E = P.tensor(512, 0, name='embedding')
+    E = P.tensor(512, 0, name='embedding', f32=True)
     P.conv(A, E, Wl.reshape(512, 7 * 7 * 512, 1, 1), bl, ch_pos=ch_pos, pad=0)
     P.outputs = [E]
     return P
@@ -355,6 +394,9 @@ def pack_retinaface(sd, precision='f32'):
     ctx5x5+ctx7x7.0, cls+bbox+landmark heads); the FPN nearest-x2 upsample + add is the
     residual of the lateral 1x1 conv's epilogue."""
     P = Program(MODEL_RETINAFACE, precision)
+    # The detector is HBM-bound and its depthwise layers and score thresholds are the most rounding-sensitive part of
+    # the path: keep every activation float32 (the conv kernels split fragments in registers instead).
+    P.allow_split = False
     tin = P.tensor(4, 1, name='input')
     P.input_tensor = tin
     eps = arch.RETINA_BASE_BN_EPS
@@ -438,7 +480,7 @@ def pack_retinaface(sd, precision='f32'):
         Wh = np.concatenate([sd['outputs.%s_stride%d.weight' % (h, s)] for h in ('cls', 'bbox', 'landmark')])
         bh = np.concatenate([sd['outputs.%s_stride%d.bias' % (h, s)] for h in ('cls', 'bbox', 'landmark')])
         pos = np.concatenate([np.arange(32), 48 + np.arange(16), 80 + np.arange(16)])
-        hd = P.tensor(16 * A, 0, name='head%d' % s)
+        hd = P.tensor(16 * A, 0, name='head%d' % s, f32=True)
         P.conv(ctx, hd, Wh, bh, ch_pos=pos, cin_p=96)
         heads[s] = hd
     P.outputs = [heads[32], heads[16], heads[8]]
