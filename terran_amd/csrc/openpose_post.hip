@@ -40,42 +40,60 @@ struct op_maps {
 
 // ---- 1. bicubic x8 ------------------------------------------------------------------------------
 // up: [N][57][8h][8w] planar; channel c<38 = PAF c, c>=38 = heat-map c-38.
+// One thread per (plane row y, source column q): the 8 outputs x = 8q..8q+7 share 4 rows x 5 source columns
+// (q-2..q+2, border-clamped), so each source value is read once per thread and the 32 output bytes are two
+// 16-byte stores; rows of a plane are contiguous across q -> fully coalesced 430 MB/step write stream.
+// Tap order per output is exactly ATen's: fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1))) on each of the 4 rows, then
+// the same chain vertically (weights depend only on the phase x%8 / y%8 and are exact in float32).
 __global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, float* up, const int* ytab, const float* ywt,
-                                                       const int* xtab, const float* xwt) {
+                                                       const float* xphase /*[8][4]*/) {
   const int H8 = m.h * 8, W8 = m.w * 8;
-  const size_t total = (size_t)N * 57 * H8 * W8;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W8);
-    size_t r = i / W8;
-    const int y = (int)(r % H8);
-    r /= H8;
-    const int c = (int)(r % 57);
-    const int img = (int)(r / 57);
-    const float* src = m.base + (size_t)img * m.img + m.off0;
-    const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
-    const int4 xi = *(const int4*)(xtab + 4 * x);
-    const float4 xw = *(const float4*)(xwt + 4 * x);
-    const int4 yi = *(const int4*)(ytab + 4 * y);
-    const float4 yw = *(const float4*)(ywt + 4 * y);
-    const int ys[4] = {yi.x, yi.y, yi.z, yi.w};
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;       // source column
+  const int y = blockIdx.y;                                  // output row
+  const int pc = blockIdx.z;                                 // img * 57 + c
+  if (q >= m.w) return;
+  const int img = pc / 57, c = pc - img * 57;
+  const float* src = m.base + (size_t)img * m.img + m.off0;
+  const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
+  const int4 yi = *(const int4*)(ytab + 4 * y);
+  const float4 yw = *(const float4*)(ywt + 4 * y);
+  const int ys[4] = {yi.x, yi.y, yi.z, yi.w};
+  int xs[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int v = q - 2 + k;
+    xs[k] = v < 0 ? 0 : (v > m.w - 1 ? m.w - 1 : v);
+  }
+  float v[4][5];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* rp = src + (size_t)ys[r] * m.row;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[r][k] = ta_ld1(rp + (size_t)xs[k] * m.pix, ch, m.fmt);
+  }
+  float out[8];
+#pragma unroll
+  for (int ph = 0; ph < 8; ++ph) {
+    const float4 xw = *(const float4*)(xphase + 4 * ph);
+    const int o = ph < 4 ? 0 : 1;                            // phases 0..3 start at column q-2, 4..7 at q-1
     float rows[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float* rp = src + (size_t)ys[k] * m.row;
-      const float v0 = ta_ld1(rp + (size_t)xi.x * m.pix, ch, m.fmt), v1 = ta_ld1(rp + (size_t)xi.y * m.pix, ch, m.fmt);
-      const float v2 = ta_ld1(rp + (size_t)xi.z * m.pix, ch, m.fmt), v3 = ta_ld1(rp + (size_t)xi.w * m.pix, ch, m.fmt);
-      float a = v1 * xw.y;
-      a = __builtin_fmaf(v0, xw.x, a);
-      a = __builtin_fmaf(v2, xw.z, a);
-      a = __builtin_fmaf(v3, xw.w, a);
-      rows[k] = a;
+    for (int r = 0; r < 4; ++r) {
+      float a = v[r][o + 1] * xw.y;
+      a = __builtin_fmaf(v[r][o + 0], xw.x, a);
+      a = __builtin_fmaf(v[r][o + 2], xw.z, a);
+      a = __builtin_fmaf(v[r][o + 3], xw.w, a);
+      rows[r] = a;
     }
-    float o = rows[1] * yw.y;
-    o = __builtin_fmaf(rows[0], yw.x, o);
-    o = __builtin_fmaf(rows[2], yw.z, o);
-    o = __builtin_fmaf(rows[3], yw.w, o);
-    up[i] = o;
+    float t = rows[1] * yw.y;
+    t = __builtin_fmaf(rows[0], yw.x, t);
+    t = __builtin_fmaf(rows[2], yw.z, t);
+    t = __builtin_fmaf(rows[3], yw.w, t);
+    out[ph] = t;
   }
+  float* dst = up + ((size_t)pc * H8 + y) * W8 + 8 * q;
+  *(float4*)dst = make_float4(out[0], out[1], out[2], out[3]);
+  *(float4*)(dst + 4) = make_float4(out[4], out[5], out[6], out[7]);
 }
 
 static void cubic_axis(int in_size, std::vector<int>& idx, std::vector<float>& wts) {
@@ -482,9 +500,12 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   {
     const size_t total = (size_t)N * 57 * H8 * W8;
     ta_prof_scope scope(ctx, 3, (double)total * 4);
-    size_t g = (total + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(bicubic_kernel, dim3((int)g), dim3(256), 0, ctx->stream, m, N, up, ytab, ywt, xtab, xwt);
+    if ((size_t)N * 57 > 65535 || H8 > 65535) return ta_fail(ctx, TA_E_INVALID, "openpose: batch too large for one upsample launch");
+    const int bx = m.w >= 256 ? 256 : 64;
+    // the x weights depend only on the phase x % 8: entries 8..15 of the table are an interior period
+    hipLaunchKernelGGL(bicubic_kernel, dim3((m.w + bx - 1) / bx, H8, N * 57), dim3(bx), 0, ctx->stream, m, N, up, ytab, ywt,
+                       xwt + (m.w >= 2 ? 32 : 0));
+    (void)xtab;
     TA_HIP(ctx, hipGetLastError());
   }
   if (up_out_host) {
