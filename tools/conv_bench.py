@@ -31,7 +31,8 @@ def bench(ctx, name, n, h, w, cin, cout, k, precision, reps=20):
     layers = 4
     for i in range(layers):
         t = P.tensor(cout, k // 2)
-        P.conv(cur, t, rng.normal(0, 1 / np.sqrt(cin * k * k), (cout, cin, k, k)).astype(np.float32),
+        wscale = 0.0 if os.environ.get('TA_BENCH_ZERO') else 1.0    # zero data: shows the DVFS/power share of a result
+        P.conv(cur, t, (wscale * rng.normal(0, 1 / np.sqrt(cin * k * k), (cout, cin, k, k))).astype(np.float32),
                np.zeros(cout, np.float32), act=pack.ACT_RELU)
         cur = t
         cin = cout
