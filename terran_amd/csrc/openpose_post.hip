@@ -40,60 +40,74 @@ struct op_maps {
 
 // ---- 1. bicubic x8 ------------------------------------------------------------------------------
 // up: [N][57][8h][8w] planar; channel c<38 = PAF c, c>=38 = heat-map c-38.
-// One thread per (plane row y, source column q): the 8 outputs x = 8q..8q+7 share 4 rows x 5 source columns
-// (q-2..q+2, border-clamped), so each source value is read once per thread and the 32 output bytes are two
-// 16-byte stores; rows of a plane are contiguous across q -> fully coalesced 430 MB/step write stream.
+// The source is NHWC (channels fastest), the result planar (x fastest): a workgroup stages the 5 source rows
+// j-2..j+2 (border-clamped) x a strip of <= BC_TW columns (+2 halo each side) x 57 channels through LDS -- global
+// reads with lanes along channels (coalesced), LDS image [row][channel][column] -- and then produces the 8 output
+// rows 8j..8j+7 of that strip for all 57 planes with lanes along x: a task = (plane, phase row, source column q)
+// makes the 8 outputs x = 8q..8q+7 from 4 rows x 5 columns of LDS and stores 32 contiguous bytes, so the
+// 430 MB/step write stream is fully coalesced and every source value is read from HBM once per workgroup.
 // Tap order per output is exactly ATen's: fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1))) on each of the 4 rows, then
 // the same chain vertically (weights depend only on the phase x%8 / y%8 and are exact in float32).
-__global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, float* up, const int* ytab, const float* ywt,
+#define BC_TW 64
+__global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, float* up, const float* ywt,
                                                        const float* xphase /*[8][4]*/) {
+  extern __shared__ float bc_sm[];
   const int H8 = m.h * 8, W8 = m.w * 8;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;       // source column
-  const int y = blockIdx.y;                                  // output row
-  const int pc = blockIdx.z;                                 // img * 57 + c
-  if (q >= m.w) return;
-  const int img = pc / 57, c = pc - img * 57;
+  const int j = blockIdx.x;                                  // source row
+  const int q0 = blockIdx.y * BC_TW;                         // first source column of the strip
+  const int img = blockIdx.z;
+  const int tw = m.w - q0 < BC_TW ? m.w - q0 : BC_TW;        // columns produced
+  const int lw = tw + 4;                                     // columns staged (q0-2 .. q0+tw+1, clamped)
+  const int WP = lw | 1;                                     // odd pitch: the transposing LDS stores spread over banks
   const float* src = m.base + (size_t)img * m.img + m.off0;
-  const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
-  const int4 yi = *(const int4*)(ytab + 4 * y);
-  const float4 yw = *(const float4*)(ywt + 4 * y);
-  const int ys[4] = {yi.x, yi.y, yi.z, yi.w};
-  int xs[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    int v = q - 2 + k;
-    xs[k] = v < 0 ? 0 : (v > m.w - 1 ? m.w - 1 : v);
+  for (int idx = threadIdx.x; idx < 5 * lw * 57; idx += 256) {
+    const int c = idx % 57;
+    const int t = idx / 57;
+    const int lc = t % lw, sr = t / lw;
+    int row = j - 2 + sr;
+    row = row < 0 ? 0 : (row > m.h - 1 ? m.h - 1 : row);
+    int col = q0 - 2 + lc;
+    col = col < 0 ? 0 : (col > m.w - 1 ? m.w - 1 : col);
+    const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
+    bc_sm[(sr * 57 + c) * WP + lc] = ta_ld1(src + (size_t)row * m.row + (size_t)col * m.pix, ch, m.fmt);
   }
-  float v[4][5];
+  __syncthreads();
+  for (int task = threadIdx.x; task < 57 * 8 * tw; task += 256) {
+    const int lq = task % tw;
+    const int t = task / tw;
+    const int ph = t & 7, c = t >> 3;
+    const int y = 8 * j + ph;
+    const float4 yw = *(const float4*)(ywt + 4 * y);
+    const int so = ph < 4 ? 0 : 1;                           // rows j-2..j+1 for phases 0..3, j-1..j+2 for 4..7
+    float v[4][5];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float* rp = src + (size_t)ys[r] * m.row;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[r][k] = ta_ld1(rp + (size_t)xs[k] * m.pix, ch, m.fmt);
-  }
-  float out[8];
+      for (int k = 0; k < 5; ++k) v[r][k] = bc_sm[((so + r) * 57 + c) * WP + lq + k];
+    float out[8];
 #pragma unroll
-  for (int ph = 0; ph < 8; ++ph) {
-    const float4 xw = *(const float4*)(xphase + 4 * ph);
-    const int o = ph < 4 ? 0 : 1;                            // phases 0..3 start at column q-2, 4..7 at q-1
-    float rows[4];
+    for (int px = 0; px < 8; ++px) {
+      const float4 xw = *(const float4*)(xphase + 4 * px);
+      const int o = px < 4 ? 0 : 1;                          // phases 0..3 start at column q-2, 4..7 at q-1
+      float rows[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a = v[r][o + 1] * xw.y;
-      a = __builtin_fmaf(v[r][o + 0], xw.x, a);
-      a = __builtin_fmaf(v[r][o + 2], xw.z, a);
-      a = __builtin_fmaf(v[r][o + 3], xw.w, a);
-      rows[r] = a;
+      for (int r = 0; r < 4; ++r) {
+        float a = v[r][o + 1] * xw.y;
+        a = __builtin_fmaf(v[r][o + 0], xw.x, a);
+        a = __builtin_fmaf(v[r][o + 2], xw.z, a);
+        a = __builtin_fmaf(v[r][o + 3], xw.w, a);
+        rows[r] = a;
+      }
+      float tt = rows[1] * yw.y;
+      tt = __builtin_fmaf(rows[0], yw.x, tt);
+      tt = __builtin_fmaf(rows[2], yw.z, tt);
+      tt = __builtin_fmaf(rows[3], yw.w, tt);
+      out[px] = tt;
     }
-    float t = rows[1] * yw.y;
-    t = __builtin_fmaf(rows[0], yw.x, t);
-    t = __builtin_fmaf(rows[2], yw.z, t);
-    t = __builtin_fmaf(rows[3], yw.w, t);
-    out[ph] = t;
+    float* dst = up + (((size_t)img * 57 + c) * H8 + y) * W8 + 8 * (q0 + lq);
+    *(float4*)dst = make_float4(out[0], out[1], out[2], out[3]);
+    *(float4*)(dst + 4) = make_float4(out[4], out[5], out[6], out[7]);
   }
-  float* dst = up + ((size_t)pc * H8 + y) * W8 + 8 * q;
-  *(float4*)dst = make_float4(out[0], out[1], out[2], out[3]);
-  *(float4*)(dst + 4) = make_float4(out[4], out[5], out[6], out[7]);
 }
 
 static void cubic_axis(int in_size, std::vector<int>& idx, std::vector<float>& wts) {
@@ -500,11 +514,20 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   {
     const size_t total = (size_t)N * 57 * H8 * W8;
     ta_prof_scope scope(ctx, 3, (double)total * 4);
-    if ((size_t)N * 57 > 65535 || H8 > 65535) return ta_fail(ctx, TA_E_INVALID, "openpose: batch too large for one upsample launch");
-    const int bx = m.w >= 256 ? 256 : 64;
+    if (N > 65535 || m.h > 65535) return ta_fail(ctx, TA_E_INVALID, "openpose: batch too large for one upsample launch");
+    const int strips = (m.w + BC_TW - 1) / BC_TW;
+    const int lw = (m.w < BC_TW ? m.w : BC_TW) + 4;
+    const size_t lds = (size_t)5 * 57 * (lw | 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      TA_HIP(ctx, hipFuncSetAttribute((const void*)bicubic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((size_t)5 * 57 * ((BC_TW + 4) | 1) * sizeof(float))));
+      attr_set = true;
+    }
     // the x weights depend only on the phase x % 8: entries 8..15 of the table are an interior period
-    hipLaunchKernelGGL(bicubic_kernel, dim3((m.w + bx - 1) / bx, H8, N * 57), dim3(bx), 0, ctx->stream, m, N, up, ytab, ywt,
+    hipLaunchKernelGGL(bicubic_kernel, dim3(m.h, strips, N), dim3(256), lds, ctx->stream, m, N, up, ywt,
                        xwt + (m.w >= 2 ? 32 : 0));
+    (void)ytab;
     (void)xtab;
     TA_HIP(ctx, hipGetLastError());
   }
