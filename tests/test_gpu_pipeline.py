@@ -175,6 +175,15 @@ def test_bicubic_bit_exact(ctx):
     assert np.array_equal(ctx.bicubic_x8(g['maps']), g['up'])     # vs torch CPU F.interpolate
 
 
+@pytest.mark.parametrize('shape', [(2, 57, 3, 70), (1, 57, 1, 1), (1, 5, 2, 129), (1, 60, 9, 64)])
+def test_bicubic_strips_and_borders_bit_exact(ctx, shape):
+    """Column strips (w > 64), strip remainders, single-row / single-pixel maps, channel groups != 57: still bitwise
+    torch's bicubic (oracle.openpose_post.bicubic_x8, pinned to F.interpolate by tests/test_oracle_golden.py)."""
+    from oracle import openpose_post
+    maps = np.random.default_rng(sum(shape)).normal(size=shape).astype(np.float32)
+    assert np.array_equal(ctx.bicubic_x8(maps), openpose_post.bicubic_x8(maps, impl='numpy'))
+
+
 def test_openpose_group_vs_reference(ctx):
     """Grouping only, on synthetic maps: keypoint assignments bit-exact vs the REFERENCE wrapper."""
     from terran_amd import openpose
