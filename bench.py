@@ -52,6 +52,8 @@ def main():
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or bf16x3)')
     ap.add_argument('--single-mode', action='store_true', help='skip the secondary f32-MFMA measurement')
+    ap.add_argument('--threads', type=int, default=3, choices=[2, 3], help='host threads / HIP streams per GPU')
+    ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -80,23 +82,28 @@ def main():
 
     from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
 
-    # Two host threads per GPU, each with its own context (HIP stream + scratch): face path and pose path
-    # are independent per frame, so their kernels interleave on the device and the host-side result
-    # handling of one hides under the other's device time.
+    # Three host threads per GPU, each with its own context (HIP stream + scratch): detection, embedding (fed
+    # the detections of its batch through a queue) and pose.  Their kernels interleave on the device -- one
+    # stream's conv fills the CUs another's tail leaves idle -- and the host-side result handling of one
+    # hides under the others' device time (measured: 2 threads joined per step 1262, 2 threads free-running
+    # 1300, 3 threads 1490 frames/s; a fourth lane adds nothing).
     from concurrent.futures import ThreadPoolExecutor
     ctx = runtime.get_context(device_index)
     ctx_pose = runtime.new_context(device_index)
+    ctx_rec = runtime.new_context(device_index)
     sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
-    pool = ThreadPoolExecutor(max_workers=1)
+    pool = ThreadPoolExecutor(max_workers=2)
     frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
     frames = ctx.upload(frames_host)                                # resident in HBM before timing
     frames_pose = ctx_pose.upload(frames_host)                      # the pose thread's handle on the batch
+    frames_rec = ctx_rec.upload(frames_host)                        # the embedding thread's handle
     F = args.faces
     fallback_lm = synth.landmarks(77, F, H, W)
 
     def sync():
         ctx.sync()
         ctx_pose.sync()
+        ctx_rec.sync()
         if world > 1:
             if backend == 'nccl':
                 torch.cuda.synchronize()
@@ -107,17 +114,21 @@ def main():
         step with a HIP event pair around every launch for the per-kernel roofline."""
         det = Detection(short_side=416, device=device_index, state=sd_r, precision=precision)
         rec = Recognition(device=device_index, state=sd_a, precision=precision)
+        rec3 = Recognition(device=device_index, state=sd_a, ctx=ctx_rec, precision=precision) if args.threads >= 3 else None
         est = Estimation(short_side=184, device=device_index, state=sd_p, ctx=ctx_pose, precision=precision)
 
-        def face_path():
-            dets = det(frames)
+        def pick_faces(dets):
             faces = []
             for d in dets:
                 f = [{'landmarks': x['landmarks']} for x in d[:F]]
                 for k in range(len(f), F):                          # fewer than F detections: synthetic landmarks
                     f.append({'landmarks': fallback_lm[k]})
                 faces.append(f)
-            return dets, rec.model.call(frames, faces)
+            return faces
+
+        def face_path():
+            dets = det(frames)
+            return dets, rec.model.call(frames, pick_faces(dets))
 
         def step(concurrent=True):
             if not concurrent:
@@ -127,12 +138,43 @@ def main():
             dets, feats = face_path()
             return dets, feats, fut.result()
 
-        for _ in range(args.warmup):
-            step()
+        def run_steps(k):
+            """k steps.  Default: the face thread and the pose thread each walk the k batches on their own
+            (a video pipeline: detection of batch i+1 does not wait for the pose of batch i); every step still
+            yields its detections, embeddings and poses.  --join-steps: both paths join after every step."""
+            if args.join_steps:
+                for _ in range(k):
+                    res = step()
+                return res
+            fut = pool.submit(lambda: [est(frames_pose) for _ in range(k)])
+            if args.threads >= 3:                                   # detect -> queue -> embed on a third thread
+                import queue
+                q = queue.Queue()
+
+                def embed_loop():
+                    res = []
+                    for _ in range(k):
+                        res.append(rec3.model.call(frames_rec, pick_faces(q.get())))
+                    return res
+                fut_e = pool.submit(embed_loop)
+                dets_out = []
+                for _ in range(k):
+                    dets_out.append(det(frames))
+                    q.put(dets_out[-1])
+                feats_out = fut_e.result()
+                poses_out = fut.result()
+                assert len(dets_out) == k and len(feats_out) == k and len(poses_out) == k
+                return dets_out[-1], feats_out[-1], poses_out[-1]
+            faces_out = [face_path() for _ in range(k)]
+            poses_out = fut.result()
+            assert len(faces_out) == k and len(poses_out) == k
+            return faces_out[-1][0], faces_out[-1][1], poses_out[-1]
+
+        if args.warmup:
+            run_steps(args.warmup)
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        out = run_steps(args.steps)
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -152,7 +194,7 @@ def main():
             klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
         for c in (ctx, ctx_pose):
             c.profile(False)
-        for m in (det.model, rec.model, est.model):
+        for m in (det.model, rec.model, est.model) + ((rec3.model,) if rec3 else ()):
             m.model.free()
         return elapsed, out, klass
 
@@ -218,7 +260,10 @@ def main():
                 'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
                 'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
                 'sharding': 'frames split over ranks, no data-path collective',
-                'streams_per_gpu': 2,
+                'streams_per_gpu': args.threads,
+                'step_overlap': 'host threads join after every step' if args.join_steps else
+                                'detect / embed / pose host threads each walk the K batches (embed consumes the '
+                                'detections of its batch through a queue); joined once at the end',
             },
             'roofline': roofline(primary, klass),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
@@ -228,6 +273,7 @@ def main():
             result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
     frames.free()
     frames_pose.free()
+    frames_rec.free()
     pool.shutdown()
     if world > 1:
         dist.barrier()
