@@ -43,7 +43,7 @@ DTYPES = {'f32': 'f32', 'bf16x3': 'f32 (activations/accumulators f32; products o
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or bf16x3)')
     ap.add_argument('--single-mode', action='store_true', help='skip the secondary f32-MFMA measurement')
-    ap.add_argument('--threads', type=int, default=3, choices=[2, 3], help='host threads / HIP streams per GPU')
+    ap.add_argument('--inflight', type=int, default=1, help='batches in flight per GPU (pipelines of 3 streams each)')
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
     args = ap.parse_args()
 
@@ -82,96 +82,118 @@ def main():
 
     from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
 
-    # Three host threads per GPU, each with its own context (HIP stream + scratch): detection, embedding (fed
-    # the detections of its batch through a queue) and pose.  Their kernels interleave on the device -- one
-    # stream's conv fills the CUs another's tail leaves idle -- and the host-side result handling of one
-    # hides under the others' device time (measured: 2 threads joined per step 1262, 2 threads free-running
-    # 1300, 3 threads 1490 frames/s; a fourth lane adds nothing).
+    # Host side: a pipeline of three host threads per GPU, each with its own context (HIP stream + scratch):
+    # detection, embedding (fed the detections of its batch through a queue) and pose.  Kernels of the streams
+    # interleave on the device -- one stream's conv fills the CUs another's tail and launch gap leave idle -- and the
+    # host-side result handling of one thread hides under the others' device time.  Measured on one MI355X
+    # (frames/s): 2 threads joined per step 1262, free-running 1300, 3 threads 1490, and 1620 once released frame
+    # buffers are parked per context instead of hipFree'd (hipFree waits for every stream of the process).
+    # `--inflight L` runs L such pipelines on alternate batches; L > 1 measured no better (1560-1580).
+    import queue
     from concurrent.futures import ThreadPoolExecutor
-    ctx = runtime.get_context(device_index)
-    ctx_pose = runtime.new_context(device_index)
-    ctx_rec = runtime.new_context(device_index)
+    # a thread coming back from a (GIL-free) library call must not wait a whole 5 ms interpreter time slice behind
+    # another thread's result handling before it can queue its next launch
+    sys.setswitchinterval(float(os.environ.get('TA_BENCH_SWITCH', '2e-4')))
     sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
-    pool = ThreadPoolExecutor(max_workers=2)
     frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
-    frames = ctx.upload(frames_host)                                # resident in HBM before timing
-    frames_pose = ctx_pose.upload(frames_host)                      # the pose thread's handle on the batch
-    frames_rec = ctx_rec.upload(frames_host)                        # the embedding thread's handle
     F = args.faces
     fallback_lm = synth.landmarks(77, F, H, W)
+    L = max(1, args.inflight)
+    pool = ThreadPoolExecutor(max_workers=3 * L)
+
+    def pick_faces(dets):
+        faces = []
+        for d in dets:
+            f = [{'landmarks': x['landmarks']} for x in d[:F]]
+            for k in range(len(f), F):                              # fewer than F detections: synthetic landmarks
+                f.append({'landmarks': fallback_lm[k]})
+            faces.append(f)
+        return faces
+
+    class Pipeline:
+        """Three streams on one GPU and this pipeline's handles on the resident batch."""
+
+        def __init__(self, first):
+            self.ctxs = [runtime.get_context(device_index) if first else runtime.new_context(device_index),
+                         runtime.new_context(device_index), runtime.new_context(device_index)]
+            self.frames = [c.upload(frames_host) for c in self.ctxs]      # resident in HBM before timing
+            self.det = self.rec = self.est = None
+
+        def load(self, precision):
+            c_det, c_rec, c_pose = self.ctxs
+            self.det = Detection(short_side=416, device=device_index, state=sd_r, ctx=c_det, precision=precision)
+            self.rec = Recognition(device=device_index, state=sd_a, ctx=c_rec, precision=precision)
+            self.est = Estimation(short_side=184, device=device_index, state=sd_p, ctx=c_pose, precision=precision)
+
+        def unload(self):
+            for m in (self.det.model, self.rec.model, self.est.model):
+                m.model.free()
+
+        def serial_step(self):
+            dets = self.det(self.frames[0])
+            return dets, self.rec.model.call(self.frames[1], pick_faces(dets)), self.est(self.frames[2])
+
+        def start(self, k):
+            """Queue k steps on this pipeline's three threads; returns a callable that joins them."""
+            if k == 0:
+                return lambda: None
+            q = queue.Queue()
+
+            def detect_loop():
+                res = []
+                for _ in range(k):
+                    res.append(self.det(self.frames[0]))
+                    q.put(res[-1])
+                return res
+
+            def embed_loop():
+                return [self.rec.model.call(self.frames[1], pick_faces(q.get())) for _ in range(k)]
+
+            def pose_loop():
+                return [self.est(self.frames[2]) for _ in range(k)]
+            futs = [pool.submit(f) for f in (detect_loop, embed_loop, pose_loop)]
+
+            def join():
+                d, e, p_ = [f.result() for f in futs]
+                assert len(d) == k and len(e) == k and len(p_) == k       # every step produced all three results
+                return d[-1], e[-1], p_[-1]
+            return join
+
+        def sync(self):
+            for c in self.ctxs:
+                c.sync()
+
+        def free(self):
+            for f in self.frames:
+                f.free()
+
+    pipes = [Pipeline(i == 0) for i in range(L)]
 
     def sync():
-        ctx.sync()
-        ctx_pose.sync()
-        ctx_rec.sync()
+        for p in pipes:
+            p.sync()
         if world > 1:
             if backend == 'nccl':
                 torch.cuda.synchronize()
             dist.barrier()
 
+    def run_steps(k):
+        """k steps, pipeline p taking steps p, p+L, ...; with --join-steps one step at a time on pipeline 0."""
+        if args.join_steps:
+            for _ in range(k):
+                res = pipes[0].start(1)()
+            return res
+        joins = [p.start(len(range(i, k, L))) for i, p in enumerate(pipes)]
+        outs = [j() for j in joins]
+        return next(o for o in outs if o is not None)
+
     def run_mode(precision):
         """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then one serial
         step with a HIP event pair around every launch for the per-kernel roofline."""
-        det = Detection(short_side=416, device=device_index, state=sd_r, precision=precision)
-        rec = Recognition(device=device_index, state=sd_a, precision=precision)
-        rec3 = Recognition(device=device_index, state=sd_a, ctx=ctx_rec, precision=precision) if args.threads >= 3 else None
-        est = Estimation(short_side=184, device=device_index, state=sd_p, ctx=ctx_pose, precision=precision)
-
-        def pick_faces(dets):
-            faces = []
-            for d in dets:
-                f = [{'landmarks': x['landmarks']} for x in d[:F]]
-                for k in range(len(f), F):                          # fewer than F detections: synthetic landmarks
-                    f.append({'landmarks': fallback_lm[k]})
-                faces.append(f)
-            return faces
-
-        def face_path():
-            dets = det(frames)
-            return dets, rec.model.call(frames, pick_faces(dets))
-
-        def step(concurrent=True):
-            if not concurrent:
-                dets, feats = face_path()
-                return dets, feats, est(frames_pose)
-            fut = pool.submit(est, frames_pose)
-            dets, feats = face_path()
-            return dets, feats, fut.result()
-
-        def run_steps(k):
-            """k steps.  Default: the face thread and the pose thread each walk the k batches on their own
-            (a video pipeline: detection of batch i+1 does not wait for the pose of batch i); every step still
-            yields its detections, embeddings and poses.  --join-steps: both paths join after every step."""
-            if args.join_steps:
-                for _ in range(k):
-                    res = step()
-                return res
-            fut = pool.submit(lambda: [est(frames_pose) for _ in range(k)])
-            if args.threads >= 3:                                   # detect -> queue -> embed on a third thread
-                import queue
-                q = queue.Queue()
-
-                def embed_loop():
-                    res = []
-                    for _ in range(k):
-                        res.append(rec3.model.call(frames_rec, pick_faces(q.get())))
-                    return res
-                fut_e = pool.submit(embed_loop)
-                dets_out = []
-                for _ in range(k):
-                    dets_out.append(det(frames))
-                    q.put(dets_out[-1])
-                feats_out = fut_e.result()
-                poses_out = fut.result()
-                assert len(dets_out) == k and len(feats_out) == k and len(poses_out) == k
-                return dets_out[-1], feats_out[-1], poses_out[-1]
-            faces_out = [face_path() for _ in range(k)]
-            poses_out = fut.result()
-            assert len(faces_out) == k and len(poses_out) == k
-            return faces_out[-1][0], faces_out[-1][1], poses_out[-1]
-
+        for p in pipes:
+            p.load(precision)
         if args.warmup:
-            run_steps(args.warmup)
+            run_steps(max(args.warmup, L))                          # every pipeline warms its plans
         sync()
         t0 = time.perf_counter()
         out = run_steps(args.steps)
@@ -181,21 +203,22 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        for c in (ctx, ctx_pose):
+        p0 = pipes[0]
+        for c in p0.ctxs:
             c.profile_reset()
             c.profile(True)
-        step(concurrent=False)
+        p0.serial_step()
         klass = {}
         for k, name in enumerate(('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')):
             ms = n = work = 0
-            for c in (ctx, ctx_pose):
+            for c in p0.ctxs:
                 a, b, w_ = c.profile_read(k)
                 ms, n, work = ms + a, n + b, work + w_
             klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
-        for c in (ctx, ctx_pose):
+        for c in p0.ctxs:
             c.profile(False)
-        for m in (det.model, rec.model, est.model) + ((rec3.model,) if rec3 else ()):
-            m.model.free()
+        for p in pipes:
+            p.unload()
         return elapsed, out, klass
 
     def roofline(precision, klass):
@@ -260,10 +283,12 @@ def main():
                 'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
                 'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
                 'sharding': 'frames split over ranks, no data-path collective',
-                'streams_per_gpu': args.threads,
-                'step_overlap': 'host threads join after every step' if args.join_steps else
-                                'detect / embed / pose host threads each walk the K batches (embed consumes the '
-                                'detections of its batch through a queue); joined once at the end',
+                'streams_per_gpu': 3 * L,
+                'batches_in_flight_per_gpu': L,
+                'step_overlap': 'one step at a time' if args.join_steps else
+                                '%d pipeline(s) of detect / embed / pose host threads, pipeline p takes steps p, p+%d, '
+                                '... (embed consumes the detections of its batch through a queue); joined once at '
+                                'the end of the timed region' % (L, L),
             },
             'roofline': roofline(primary, klass),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
@@ -271,9 +296,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
-    frames.free()
-    frames_pose.free()
-    frames_rec.free()
+    for p in pipes:
+        p.free()
     pool.shutdown()
     if world > 1:
         dist.barrier()

@@ -124,6 +124,7 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& e : ctx->frame_cache) (void)hipFree(e.second);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -309,6 +310,9 @@ void ta_host_free(ta_ctx* ctx, void* ptr) {
   if (ptr) (void)hipHostFree(ptr);
 }
 
+// parked frame buffers per context: a handful of recent sizes, bounded in bytes
+#define TA_FRAME_CACHE_SLOTS 8
+#define TA_FRAME_CACHE_BYTES ((size_t)2 << 30)
 static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames** out);
 
 int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
@@ -321,11 +325,24 @@ static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames**
   ta_frames* f = new ta_frames{ctx, n, h, w, nullptr};
   size_t bytes = (size_t)n * h * w * 3;
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc((void**)&f->dev, bytes);
-  if (e != hipSuccess) {
-    delete f;
-    return ta_fail(ctx, TA_E_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  {
+    std::lock_guard<std::mutex> lock(ctx->frame_cache_mu);
+    for (size_t i = 0; i < ctx->frame_cache.size(); ++i)
+      if (ctx->frame_cache[i].first == bytes) {
+        f->dev = (uint8_t*)ctx->frame_cache[i].second;
+        ctx->frame_cache_bytes -= bytes;
+        ctx->frame_cache.erase(ctx->frame_cache.begin() + i);
+        break;
+      }
   }
+  if (!f->dev) {
+    hipError_t e = hipMalloc((void**)&f->dev, bytes);
+    if (e != hipSuccess) {
+      delete f;
+      return ta_fail(ctx, TA_E_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+  }
+  f->cap = bytes;
   if (zero) TA_HIP(ctx, hipMemsetAsync(f->dev, 0, bytes, ctx->stream));   // only pad-merge canvases need zeros
   *out = f;
   return TA_OK;
@@ -365,8 +382,23 @@ int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb) {
 void ta_frames_free(ta_frames* f) {
   ta_enter(f ? f->ctx : nullptr);
   if (!f) return;
-  (void)hipStreamSynchronize(f->ctx->stream);
-  if (f->dev) (void)hipFree(f->dev);
+  ta_ctx* ctx = f->ctx;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (f->dev) {
+    // every entry point is synchronous at its end, so the buffer is idle here: park it for the next batch
+    std::vector<void*> evict;
+    {
+      std::lock_guard<std::mutex> lock(ctx->frame_cache_mu);
+      ctx->frame_cache.emplace_back(f->cap, f->dev);
+      ctx->frame_cache_bytes += f->cap;
+      while (ctx->frame_cache.size() > TA_FRAME_CACHE_SLOTS || ctx->frame_cache_bytes > TA_FRAME_CACHE_BYTES) {
+        ctx->frame_cache_bytes -= ctx->frame_cache.front().first;
+        evict.push_back(ctx->frame_cache.front().second);
+        ctx->frame_cache.erase(ctx->frame_cache.begin());
+      }
+    }
+    for (void* p : evict) (void)hipFree(p);
+  }
   delete f;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,11 @@ struct ta_ctx {
   size_t scratch_bytes = 0;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // released frame buffers, kept for the next batch of the same size: hipFree waits for the whole device (every
+  // stream of the process), which serialises the per-GPU host threads once per resize otherwise
+  std::mutex frame_cache_mu;                       // frames may be released from a GC thread
+  std::vector<std::pair<size_t, void*>> frame_cache;
+  size_t frame_cache_bytes = 0;
 };
 
 int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...);
@@ -119,6 +125,7 @@ struct ta_frames {
   ta_ctx* ctx;
   int n, h, w;
   uint8_t* dev;
+  size_t cap = 0;          // bytes allocated
 };
 
 // ---------------------------------------------------------------------------------------------
