@@ -292,6 +292,10 @@ def main():
             },
             'roofline': roofline(primary, klass),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
+            # algorithmic bytes / kernel time of the HBM-bound kernel classes (peak 8000 GB/s); post-processing
+            # mixes the 430 MB x8-upsample stream with latency-bound selection / grouping kernels
+            'stage_hbm_gbps': {k: round(v['work'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in klass.items()
+                               if k != 'conv_igemm' and v['ms'] > 0},
             'other_precisions': others,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -42,6 +42,16 @@ enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Block b runs on XCD b % 8 (each XCD has its own L2).  XCD x owns a CONTIGUOUS run of pixel tiles (balanced split
+// of n_pt over the 8 XCDs), walked cout-tile fastest: the workgroups of one XCD that are in flight together work on
+// neighbouring image rows, so the 3x3 / 7x7 halo rows and the activation tile shared by all cout tiles are fetched
+// into ONE L2 once instead of into up to 8 of them.
+__device__ __forceinline__ int ta_xcd_tile(int n_pt, int xcd, int local) {
+  const int base = n_pt >> 3, rem = n_pt & 7;
+  if (local >= base + (xcd < rem ? 1 : 0)) return -1;
+  return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+
 // Fused epilogue shared by both kernels.  acc[a][b][r]: pixel = tile col (lane&31);
 // cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the 32x32 tile.
 template <int WM_TILES, int WN_TILES>
@@ -174,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   const int bid = blockIdx.x;
   const int grp = bid >> 3, xcd = bid & 7;
   const int ct = grp % n_ct;
-  const int pt = (grp / n_ct) * 8 + xcd;
   const int n_pt = (p.M + BM - 1) / BM;
-  if (pt >= n_pt) return;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
   const int ct0 = ct * BN;
   const int pt0 = pt * BM;
 
@@ -354,9 +364,9 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
   const int bid = blockIdx.x;
   const int grp = bid >> 3, xcd = bid & 7;
   const int ct = grp % n_ct;
-  const int pt = (grp / n_ct) * 8 + xcd;
   const int n_pt = (p.M + BM - 1) / BM;
-  if (pt >= n_pt) return;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
   const int ct0 = ct * BN;
   const int pt0 = pt * BM;
 
