@@ -71,7 +71,8 @@ def main():
     backend = os.environ.get('TA_BENCH_BACKEND', 'nccl')
     n_dev = max(torch.cuda.device_count(), 1)
     device_index = local_rank % n_dev
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get('TA_BENCH_FORCE_DIST'))     # FORCE: exercise the RCCL calls at N=1
+    if use_dist:
         import torch.distributed as dist
         if backend == 'nccl':
             torch.cuda.set_device(device_index)
@@ -172,7 +173,7 @@ def main():
     def sync():
         for p in pipes:
             p.sync()
-        if world > 1:
+        if use_dist:
             if backend == 'nccl':
                 torch.cuda.synchronize()
             dist.barrier()
@@ -199,7 +200,7 @@ def main():
         out = run_steps(args.steps)
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -303,7 +304,7 @@ def main():
     for p in pipes:
         p.free()
     pool.shutdown()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -1,6 +1,6 @@
 """Randomised conv cases through the checker of tests/test_gpu_conv.py (run on the GPU box).
 
-    python tools/conv_fuzz.py [n_cases] [seed]
+    python tests/fuzz_conv.py [n_cases] [seed]
 Shapes the networks never use are drawn on purpose: 1x1 .. 33x47 maps, batch 1..5, channel counts around the
 32 / 64 / 128 tile edges, channel slices, strides, all epilogue variants.  Prints the failing case dicts."""
 import os

@@ -1,6 +1,6 @@
 """Randomised post-processing parity: device (HIP) vs oracle, exact comparisons (run on the GPU box).
 
-    python tools/post_fuzz.py [rounds] [seed]
+    python tests/fuzz_post.py [rounds] [seed]
 * RetinaFace decode + threshold + sort + NMS on random head tensors (dw = dh = 0 so exp() is exact and every IoU
   comparison bit-identical; thresholds hit exactly; score ties; 0 .. thousands of candidates).
 * OpenPose grouping on synthetic pose maps: random people counts, map sizes, scales, noise levels, dropped parts.
