@@ -56,6 +56,12 @@ def main():
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): everything libraries print to fd 1 (RCCL's version banner, for
+    # one) is sent to stderr instead, and the result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -308,7 +314,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + '\n').encode())
+    os.close(real_stdout)
 
 
 def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
