@@ -1,19 +1,20 @@
-// Implicit-GEMM convolution for gfx950 (CDNA4), float32 in / float32 accumulate on the
-// exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TF peak).
+// Implicit-GEMM convolution for gfx950 (CDNA4): float32 accumulate on the exact-f32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TF peak) or on the bf16 pipe with split operands
+// (x = hi + lo, three v_mfma_f32_32x32x16_bf16 per product term: float32-class accuracy; modes below).
 //
 // One kernel serves every dense conv of the three networks (RetinaFace 1x1/3x3,
 // ArcFace 3x3 s1/s2 + 1x1 s2 shortcut + FC, OpenPose 3x3/7x7/1x1):
 //
 //   D[cout][pixel] = sum_k  W[cout][k] * X[k][pixel],     k = (ky, kx, cin)
 //
-// * Activations are NHWC float32 with a physical zero halo, so a filter tap is a constant
+// * Activations are NHWC, 4 bytes per element, with a physical zero halo, so a filter tap is a constant
 //   byte offset from a pixel's base address: no bounds checks in the K loop, and padding
 //   costs nothing (reference convs are all "same"/zero padded, e.g. openpose/model.py:6-24).
 // * K is cut in slabs of 32 floats = 8 chunks of 16 B; `ktab[slab*8+chunk]` is the byte offset
 //   (tap + channel) of that chunk from the pixel base.  One table covers 1x1, 3x3, 7x7, strided,
 //   channel-sliced and tiny-Cin (several taps per slab) convs alike.
 // * Both operands are DMA'd straight into LDS with global_load_lds (16 B per lane, no VGPR
-//   round trip), double buffered: slab s+1 streams in under the 64-cycle MFMAs of slab s.
+//   round trip), 2 or 3 LDS stages: later slabs stream in under the MFMAs of slab s.
 //   The LDS image of a tile row is 128 B; the chunk a lane fetches is XOR-swizzled with
 //   (row>>1)&7 on the SOURCE address (the DMA destination is lane-linear), which makes the
 //   ds_read_b128 fragment reads bank-conflict free.
@@ -29,14 +30,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Arithmetic modes of the MFMA inner loop (activations are float32 in HBM and LDS in every mode):
+// Arithmetic modes of the MFMA inner loop (activation tensors are float32, or pre-split bf16 hi|lo words in the
+// bf16 modes: act_format.h):
 //   PREC_F32    : v_mfma_f32_32x32x2_f32, exact f32 products.                          157 TF peak
 //   PREC_BF16X3 : x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
 //                 v_mfma_f32_32x32x16_bf16, f32 accumulate: ~1e-5 relative per product,
 //                 i.e. float32-class accuracy at 3/16 of the f32 MFMA cost.              833 TF-equivalent peak
 //   PREC_BF16   : hi*hi only (throughput mode, NOT within the 1e-3 parity bar).          2.5 PF peak
-// Weights are split at pack time ([hi x32 | lo x32] bf16 per 128-byte row); activation fragments are
-// split in registers right after the ds_read (v_cvt_pk_bf16_f32).
+// Weights are split at pack time ([hi x32 | lo x32] bf16 per 128-byte row).  Activations either arrive in the same
+// image (TA_FMT_SPLIT, written by the producer's epilogue) or are float32 and split in registers right after the
+// ds_read (v_cvt_pk_bf16_f32).
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -81,10 +84,9 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
     const int pixc = pix_raw < p.M ? pix_raw : 0;
     const int img = pixc / HoWo;
     const int rem = pixc - img * HoWo;
-    const int y = rem / p.Wq;
-    const int xr = rem - y * p.Wq;
-    const bool pix_ok = pix_raw < p.M && xr < p.Wo;      // Wq > Wo: row-run kernel computes (discarded) halo columns
-    const int x = xr < p.Wo ? xr : 0;
+    const int y = rem / p.Wo;
+    const int x = rem - y * p.Wo;
+    const bool pix_ok = pix_raw < p.M;
     f32x4 v[WM_TILES][4];
 #pragma unroll
     for (int a = 0; a < WM_TILES; ++a)

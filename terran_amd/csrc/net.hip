@@ -227,7 +227,6 @@ int ta_model_run_ops(ta_model* m) {
         p.k_cblocks = op.cin / 32;
         p.k_w = op.kw;
         p.k_h = op.kh;
-        p.Wq = to.w;
         p.in_ch_off = op.in_ch_off;
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;

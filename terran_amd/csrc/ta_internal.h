@@ -154,8 +154,7 @@ struct ta_conv_launch {
   const float* scale2;
   const float* shift2;
   int M, Ho, Wo, n_slabs, coutp, cout, act, stride, prec;
-  int uniform_k, k_cblocks, k_w, k_h, in_ch_off;
-  int Wq;                                      // pixel decomposition width (== Wo except in the row-run kernel)   // cin % 32 == 0: slabs walk (channel block, kx, ky) without a table
+  int uniform_k, k_cblocks, k_w, k_h, in_ch_off;   // uniform_k: cin % 32 == 0, slabs walk (channel block, kx, ky) without a table
   // element strides / pixel offsets (channel offsets are separate: the split format is not linear in the channel)
   int in_img, in_row, in_pix, in_off0;
   int out_img, out_row, out_pix, out_off0, out_ch, out_fmt;
