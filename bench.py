@@ -53,6 +53,10 @@ def main():
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or bf16x3)')
     ap.add_argument('--single-mode', action='store_true', help='skip the secondary f32-MFMA measurement')
     ap.add_argument('--inflight', type=int, default=1, help='batches in flight per GPU (pipelines of 3 streams each)')
+    ap.add_argument('--serial', action='store_true',
+                    help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
+                         'rocprofv3 kernel statistics under profiles/ are taken in, so that their per-kernel averages '
+                         'are comparable with the HIP-event roofline figures')
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
     args = ap.parse_args()
 
@@ -186,6 +190,10 @@ def main():
 
     def run_steps(k):
         """k steps, pipeline p taking steps p, p+L, ...; with --join-steps one step at a time on pipeline 0."""
+        if args.serial:
+            for _ in range(k):
+                res = pipes[0].serial_step()
+            return res
         if args.join_steps:
             for _ in range(k):
                 res = pipes[0].start(1)()
@@ -292,7 +300,8 @@ def main():
                 'sharding': 'frames split over ranks, no data-path collective',
                 'streams_per_gpu': 3 * L,
                 'batches_in_flight_per_gpu': L,
-                'step_overlap': 'one step at a time' if args.join_steps else
+                'step_overlap': 'serial: one kernel at a time' if args.serial else
+                                'one step at a time' if args.join_steps else
                                 '%d pipeline(s) of detect / embed / pose host threads, pipeline p takes steps p, p+%d, '
                                 '... (embed consumes the detections of its batch through a queue); joined once at '
                                 'the end of the timed region' % (L, L),
