@@ -45,6 +45,16 @@ enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// 16 B per lane global -> LDS, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset (ONE VGPR),
+// LDS destination (wave-uniform) through M0.  The two-VGPR address form the builtin emits costs the DMA stream a
+// quarter of its rate when MFMAs run on the same SIMD (VGPR read-port contention; tools/probe/dma_mfma_probe.hip:
+// 4.8 vs 6.0 B/clk per issuing wave), the saddr form none.
+__device__ __forceinline__ void ta_dma16(const char* ubase, unsigned lane_off, const float* lds_dst) {
+  const unsigned ldsa = (unsigned)(size_t)LDS_PTR(lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ubase), "s"(ldsa)
+               : "memory", "m0");
+}
+
 // Block b runs on XCD b % 8 (each XCD has its own L2).  XCD x owns a CONTIGUOUS run of pixel tiles (balanced split
 // of n_pt over the 8 XCDs), walked cout-tile fastest: the workgroups of one XCD that are in flight together work on
 // neighbouring image rows, so the 3x3 / 7x7 halo rows and the activation tile shared by all cout tiles are fetched
@@ -602,6 +612,220 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
   conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
 }
 
+
+// ---- split-role kernel (pre-split bf16 activations; 128 x 128 tiles, or 64 cout x 256 px) -----------
+// Measured with tools/probe/*: the global -> LDS DMA path sustains at most ~34 B/clk/CU however many slabs are in
+// flight (24 with only 4 issuing waves), and MFMA issue is NOT slowed by DMA waves on the same SIMD -- but a wave
+// that has to issue its own DMA stalls in front of the saturated texture addresser with its MFMAs queued behind.
+// So the roles are split: waves 0..3 (one per SIMD) are CONSUMERS, each owning a 64 x 64 register tile (4 MFMA
+// tiles, 24 MFMAs per slab in bf16x3) and doing nothing but ds_read + MFMA; waves 4..4+NP-1 are PRODUCERS that walk
+// K and issue the LDS-DMA for the whole 128 x 128 workgroup tile (32 KiB per slab -> 1.5x the FLOPs per DMA byte of
+// the 64 x 128 kernel above).  One s_barrier per slab hands a landed slab to the consumers and a drained stage back
+// to the producers.  The consumer loop is software-pipelined at k-step (16) granularity with the barrier in the
+// middle, so both fragment reads of a slab hide under 12 MFMAs each and only two 8-fragment sets are live.
+template <int CM, int NP, int PREC, int STAGES>
+__global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_split(const ta_conv_launch p) {
+  static_assert(PREC != PREC_F32, "pre-split bf16 operands only");
+  static_assert(NP == 4 || NP == 8, "4 or 8 producer waves");
+  static_assert(CM == 1 || CM == 2, "consumer grid 1x4 (64 cout x 256 px) or 2x2 (128 x 128)");
+  constexpr int CN = 4 / CM;
+  constexpr int BN = CM * 64, BM = CN * 64;
+  constexpr int NI = (BN + BM) / 8 / NP;         // DMA instructions per producer wave per slab
+  constexpr int QA = BN / 8 / NP;                // ... of which weight rows
+  constexpr int STAGE = (BN + BM) * 32;          // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int n_ct = p.coutp / BN;
+  const int bid = blockIdx.x;
+  const int grp = bid >> 3, xcd = bid & 7;
+  const int ct = grp % n_ct;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
+  const int ct0 = ct * BN;
+  const int pt0 = pt * BM;
+  const int HoWo = p.Ho * p.Wo;
+  const int S = p.n_slabs;
+
+  if (wave >= 4) {
+    // ================= producer =================
+    const int pw = wave - 4;
+    const int pchunk = lane & 7;
+    const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
+    // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR): the saddr form of global_load_lds
+    const char* a_base = (const char*)p.w;
+    unsigned a_off[QA > 0 ? QA : 1];
+    unsigned b_off[NI - QA];
+    // pixel rows: offsets relative to the tile's first pixel (pixels of a tile ascend in raster order)
+    const int img0 = pt0 / HoWo;
+    const int rem0 = pt0 - img0 * HoWo;
+    const int y0 = rem0 / p.Wo, x0 = rem0 - y0 * p.Wo;
+    const size_t off0 = (size_t)img0 * p.in_img + (size_t)(y0 * p.stride) * p.in_row + (size_t)(x0 * p.stride) * p.in_pix +
+                        p.in_off0 + p.in_ch_off;
+    const char* b_base = (const char*)(p.in + off0);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int row = (q * NP + pw) * 8 + (lane >> 3);      // row of the stage image: [BN weight rows | BM pixel rows]
+      if (q < QA) {
+        a_off[q] = (unsigned)(((ct0 + row) * 32 + lchunk * 4) * 4);
+      } else {
+        int pix = pt0 + row - BN;
+        if (pix >= p.M) pix = pt0;
+        const int img = pix / HoWo;
+        const int rem = pix - img * HoWo;
+        const int y = rem / p.Wo;
+        const int x = rem - y * p.Wo;
+        const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row +
+                           (size_t)(x * p.stride) * p.in_pix + p.in_off0 + p.in_ch_off;
+        b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
+      }
+    }
+    const size_t a_slab_bytes = (size_t)p.coutp * 128;
+    int k_cb = 0, k_x = 0, k_off = 0;
+    const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
+    auto issue = [&](int s, int stage) {
+      float* base = lds + stage * STAGE;
+      const char* ua = a_base + (size_t)s * a_slab_bytes;
+      const char* ub = b_base + k_off;
+#pragma unroll
+      for (int q = 0; q < NI; ++q) {
+        const int t = q * NP + pw;
+        ta_dma16(q < QA ? ua : ub, q < QA ? a_off[q < QA ? q : 0] : b_off[q < QA ? 0 : q - QA], base + t * 256);
+      }
+      ++k_cb;
+      k_off += 128;
+      if (k_cb == p.k_cblocks) {
+        k_cb = 0;
+        k_off += pix_bytes - p.k_cblocks * 128;
+        if (++k_x == p.k_w) {
+          k_x = 0;
+          k_off += row_bytes - p.k_w * pix_bytes;
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+      if (i < S) issue(i, i);
+    int stage = STAGES - 1;                         // stage the next issued slab goes to
+    for (int s = 0; s < S; ++s) {
+      const int rem = S - 1 - s;                    // slabs younger than s already issued: min(rem, STAGES-2)
+      if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
+      else if (STAGES == 4 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // B_s: slab s landed (all producers); consumers have drained slab s-1
+      asm volatile("" ::: "memory");
+      if (s + STAGES - 1 < S) issue(s + STAGES - 1, stage);
+      stage = stage + 1 == STAGES ? 0 : stage + 1;
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  const int cm = wave / CN, cn = wave % CN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int kg = lane >> 5;
+  const int a_row0 = cm * 64 + frow;
+  const int b_row0 = BN + cn * 64 + frow;
+  struct Frag {                                     // one k-step (16) of a slab
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+  };
+  auto load = [&](Frag& f, const float* st, int t) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+      if constexpr (PREC == PREC_BF16X3) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f.bh[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+      if constexpr (PREC == PREC_BF16X3) f.bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+    }
+  };
+  auto mma = [&](const Frag& f) {
+    if constexpr (PREC == PREC_BF16X3) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+  };
+  constexpr int NREAD = PREC == PREC_BF16X3 ? 8 : 4;       // ds_read_b128 per k-step
+  constexpr int NMMA = PREC == PREC_BF16X3 ? 12 : 4;       // MFMAs per k-step
+  // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
+  // use to save registers and exposes the LDS latency in front of every group of MFMAs
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < NREAD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMMA - NREAD, 0);
+  };
+  Frag F0, F1;
+  __builtin_amdgcn_s_barrier();                     // B_0: slab 0 visible
+  asm volatile("" ::: "memory");
+  load(F0, lds, 0);
+  int stage = 0;
+  for (int s = 0; s + 1 < S; ++s) {                 // branch-free body; the last slab is peeled below
+    const float* st = lds + stage * STAGE;
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    load(F1, st, 1);                                // second k-step of slab s under the MFMAs of the first
+    mma(F0);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment of slab s is in registers
+    __builtin_amdgcn_s_barrier();                          // B_{s+1}: slab s+1 visible, stage of slab s handed back
+    asm volatile("" ::: "memory");
+    load(F0, lds + stage * STAGE, 0);               // first k-step of slab s+1 under the MFMAs of the second
+    mma(F1);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load(F1, lds + stage * STAGE, 1);
+  mma(F0);
+  mma(F1);
+  conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
+}
+
+template <int CM, int NP, int PREC, int STAGES>
+static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
+  constexpr int BN = CM * 64, BM = (4 / CM) * 64;
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int groups = ((n_pt + 7) / 8) * n_ct;
+  const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
+  auto kern = conv_igemm_split<CM, NP, PREC, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
@@ -643,10 +867,18 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
 
 template <int PREC>
 static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
-  // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles)
+  // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles,
+  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31..33 = split-role variants)
   static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
   if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
     if constexpr (PREC != PREC_F32) {
+      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 128 == 0 && cfg != 1) {
+        if (cfg == 31) return launch_split<2, 8, PREC, 3>(ctx, p);
+        if (cfg == 32) return launch_split<2, 8, PREC, 4>(ctx, p);
+        if (cfg == 33) return launch_split<2, 4, PREC, 4>(ctx, p);
+        return launch_split<2, 4, PREC, 3>(ctx, p);
+      }
+      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, PREC, 3>(ctx, p);
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
     }
     if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");

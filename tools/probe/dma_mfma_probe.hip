@@ -11,6 +11,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+template <int SADDR>
 __global__ __launch_bounds__(512, 2) void probe(const char* src, size_t span, int slabs, int n_mfma, unsigned dma_mask,
                                                 unsigned mfma_mask, float* sink, long long* cycles) {
   extern __shared__ float lds[];
@@ -26,7 +27,15 @@ __global__ __launch_bounds__(512, 2) void probe(const char* src, size_t span, in
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         size_t o = (off + (size_t)q * 1024 + (size_t)s * 65536) % span;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(lp + o), LDS_PTR(base + q * 256), 16, 0, 0);
+        if constexpr (SADDR) {
+          // uniform 64-bit base in SGPRs + one 32-bit offset VGPR (saddr form); M0 = LDS destination
+          const char* ub = src + o;
+          const unsigned lo = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
+          const unsigned ldsa = (unsigned)(size_t)LDS_PTR(base + q * 256);
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lo), "s"(ub), "s"(ldsa) : "memory", "m0");
+        } else {
+          __builtin_amdgcn_global_load_lds(GLB_PTR(lp + o), LDS_PTR(base + q * 256), 16, 0, 0);
+        }
       }
     };
     issue(0);
@@ -56,17 +65,18 @@ __global__ __launch_bounds__(512, 2) void probe(const char* src, size_t span, in
   if (lane == 0 && blockIdx.x == 0) cycles[wave] = t1 - t0;
 }
 
+template <int SADDR>
 static void run(const char* buf, size_t span, unsigned dma_mask, unsigned mfma_mask, const char* what, float* sink,
                 long long* cyc_dev) {
   const int slabs = 3000, n_mfma = 40000;
   const size_t lds = 8 * 2 * 4 * 1024;
-  hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)probe<SADDR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  hipLaunchKernelGGL(probe, dim3(256), dim3(512), lds, 0, buf, span, 20, 100, dma_mask, mfma_mask, sink, cyc_dev);
+  hipLaunchKernelGGL(probe<SADDR>, dim3(256), dim3(512), lds, 0, buf, span, 20, 100, dma_mask, mfma_mask, sink, cyc_dev);
   hipEventRecord(a);
-  hipLaunchKernelGGL(probe, dim3(256), dim3(512), lds, 0, buf, span, slabs, n_mfma, dma_mask, mfma_mask, sink, cyc_dev);
+  hipLaunchKernelGGL(probe<SADDR>, dim3(256), dim3(512), lds, 0, buf, span, slabs, n_mfma, dma_mask, mfma_mask, sink, cyc_dev);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms = 0;
@@ -92,13 +102,16 @@ int main() {
   hipMemset(buf, 1, span + (4 << 20));
   hipMalloc((void**)&sink, 64);
   hipMalloc((void**)&cyc, 64);
-  run(buf, span, 0x00, 0xF0, "mfma only: waves 4-7 (one per SIMD)", sink, cyc);
-  run(buf, span, 0x00, 0xFF, "mfma only: all 8 waves (two per SIMD)", sink, cyc);
-  run(buf, span, 0x0F, 0x00, "dma only: waves 0-3 (one per SIMD)", sink, cyc);
-  run(buf, span, 0xFF, 0x00, "dma only: all 8 waves", sink, cyc);
-  run(buf, span, 0x0F, 0xF0, "dma 0-3 + mfma 4-7 (SHARED SIMDs)", sink, cyc);
-  run(buf, span, 0x33, 0xCC, "dma {0,1,4,5} + mfma {2,3,6,7} (SEPARATE SIMDs)", sink, cyc);
-  run(buf, span, 0x03, 0xF0, "dma 0-1 + mfma 4-7", sink, cyc);
-  run(buf, span, 0x01, 0xF0, "dma 0 + mfma 4-7", sink, cyc);
+  run<1>(buf, span, 0x0F, 0x00, "SADDR dma only: waves 0-3", sink, cyc);
+  run<1>(buf, span, 0xFF, 0x00, "SADDR dma only: all 8 waves", sink, cyc);
+  run<1>(buf, span, 0x0F, 0xF0, "SADDR dma 0-3 + mfma 4-7 (SHARED SIMDs)", sink, cyc);
+  run<0>(buf, span, 0x00, 0xF0, "mfma only: waves 4-7 (one per SIMD)", sink, cyc);
+  run<0>(buf, span, 0x00, 0xFF, "mfma only: all 8 waves (two per SIMD)", sink, cyc);
+  run<0>(buf, span, 0x0F, 0x00, "dma only: waves 0-3 (one per SIMD)", sink, cyc);
+  run<0>(buf, span, 0xFF, 0x00, "dma only: all 8 waves", sink, cyc);
+  run<0>(buf, span, 0x0F, 0xF0, "dma 0-3 + mfma 4-7 (SHARED SIMDs)", sink, cyc);
+  run<0>(buf, span, 0x33, 0xCC, "dma {0,1,4,5} + mfma {2,3,6,7} (SEPARATE SIMDs)", sink, cyc);
+  run<0>(buf, span, 0x03, 0xF0, "dma 0-1 + mfma 4-7", sink, cyc);
+  run<0>(buf, span, 0x01, 0xF0, "dma 0 + mfma 4-7", sink, cyc);
   return 0;
 }
