@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 }
 
 
-// ---- split-role kernel (pre-split bf16 activations; 128 x 128 tiles, or 64 cout x 256 px) -----------
+// ---- split-role kernel (f32 mode, or bf16 modes on pre-split activations; 128 x 128 or 64 x 256 tiles) --
 // Measured with tools/probe/*: the global -> LDS DMA path sustains at most ~34 B/clk/CU however many slabs are in
 // flight (24 with only 4 issuing waves), and MFMA issue is NOT slowed by DMA waves on the same SIMD -- but a wave
 // that has to issue its own DMA stalls in front of the saturated texture addresser with its MFMAs queued behind.
@@ -625,7 +625,6 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 // middle, so both fragment reads of a slab hide under 12 MFMAs each and only two 8-fragment sets are live.
 template <int CM, int NP, int PREC, int STAGES>
 __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_split(const ta_conv_launch p) {
-  static_assert(PREC != PREC_F32, "pre-split bf16 operands only");
   static_assert(NP == 4 || NP == 8, "4 or 8 producer waves");
   static_assert(CM == 1 || CM == 2, "consumer grid 1x4 (64 cout x 256 px) or 2x2 (128 x 128)");
   constexpr int CN = 4 / CM;
@@ -739,9 +738,22 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   const int a_row0 = cm * 64 + frow;
   const int b_row0 = BN + cn * 64 + frow;
   struct Frag {                                     // one k-step (16) of a slab
-    bf16x8 ah[2], al[2], bh[2], bl[2];
+    bf16x8 ah[2], al[2], bh[2], bl[2];              // bf16 modes: operands pre-split in LDS
+    f32x4 a32[2][2], b32[2][2];                     // f32 mode: lane (row, kg) holds k = 16 kg + 8 t + 0..7
   };
+  const int fcb = kg * 4;
   auto load = [&](Frag& f, const float* st, int t) {
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int pc = ((fcb + 2 * t + g) ^ fsw) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) f.a32[a][g] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) f.b32[b][g] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+      }
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
@@ -754,6 +766,18 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     }
   };
   auto mma = [&](const Frag& f) {
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a32[a][g][e], f.b32[b][g][e], acc[a][b], 0, 0, 0);
+      return;
+    }
     if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -769,8 +793,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
   };
-  constexpr int NREAD = PREC == PREC_BF16X3 ? 8 : 4;       // ds_read_b128 per k-step
-  constexpr int NMMA = PREC == PREC_BF16X3 ? 12 : 4;       // MFMAs per k-step
+  constexpr int NREAD = PREC == PREC_BF16 ? 4 : 8;                               // ds_read_b128 per k-step
+  constexpr int NMMA = PREC == PREC_F32 ? 32 : (PREC == PREC_BF16X3 ? 12 : 4);   // MFMAs per k-step
   // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
   // use to save registers and exposes the LDS latency in front of every group of MFMAs
   auto pin = [&]() {
@@ -882,6 +906,10 @@ static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
     }
     if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
+    if constexpr (PREC == PREC_F32) {
+      if (p.coutp % 128 == 0 && cfg != 1) return launch_split<2, 4, PREC, 3>(ctx, p);
+      if (p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, PREC, 3>(ctx, p);
+    }
     if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
     if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
   }
