@@ -638,15 +638,14 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  // Persistent workgroups: block b (XCD b % 8) walks the tile groups b >> 3, + gridDim.x >> 3, ... of its XCD.
+  // The stage ring and the barrier protocol simply continue across tiles, so the producers stream the first slabs
+  // of the next tile while the consumers run the epilogue of the current one.
   const int n_ct = p.coutp / BN;
-  const int bid = blockIdx.x;
-  const int grp = bid >> 3, xcd = bid & 7;
-  const int ct = grp % n_ct;
+  const int xcd = blockIdx.x & 7;
   const int n_pt = (p.M + BM - 1) / BM;
-  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
-  if (pt < 0) return;
-  const int ct0 = ct * BN;
-  const int pt0 = pt * BM;
+  const int n_grp = ((n_pt + 7) >> 3) * n_ct;
+  const int grp_step = gridDim.x >> 3;
   const int HoWo = p.Ho * p.Wo;
   const int S = p.n_slabs;
 
@@ -655,6 +654,12 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     const int pw = wave - 4;
     const int pchunk = lane & 7;
     const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
+    int stage = 0;                                  // stage the next issued slab goes to (runs on across tiles)
+    for (int grp = blockIdx.x >> 3; grp < n_grp; grp += grp_step) {
+    const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+    if (pt < 0) continue;
+    const int ct0 = (grp % n_ct) * BN;
+    const int pt0 = pt * BM;
     // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR): the saddr form of global_load_lds
     const char* a_base = (const char*)p.w;
     unsigned a_off[QA > 0 ? QA : 1];
@@ -708,8 +713,10 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     };
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
-      if (i < S) issue(i, i);
-    int stage = STAGES - 1;                         // stage the next issued slab goes to
+      if (i < S) {
+        issue(i, stage);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+      }
     for (int s = 0; s < S; ++s) {
       const int rem = S - 1 - s;                    // slabs younger than s already issued: min(rem, STAGES-2)
       if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
@@ -717,14 +724,23 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // B_s: slab s landed (all producers); consumers have drained slab s-1
       asm volatile("" ::: "memory");
-      if (s + STAGES - 1 < S) issue(s + STAGES - 1, stage);
-      stage = stage + 1 == STAGES ? 0 : stage + 1;
+      if (s + STAGES - 1 < S) {
+        issue(s + STAGES - 1, stage);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+      }
+    }
     }
     return;
   }
 
   // ================= consumer =================
   const int cm = wave / CN, cn = wave % CN;
+  int stage = 0;                                    // stage of the slab being consumed (runs on across tiles)
+  for (int grp = blockIdx.x >> 3; grp < n_grp; grp += grp_step) {
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) continue;
+  const int ct0 = (grp % n_ct) * BN;
+  const int pt0 = pt * BM;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -808,8 +824,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   Frag F0, F1;
   __builtin_amdgcn_s_barrier();                     // B_0: slab 0 visible
   asm volatile("" ::: "memory");
-  load(F0, lds, 0);
-  int stage = 0;
+  load(F0, lds + stage * STAGE, 0);
   for (int s = 0; s + 1 < S; ++s) {                 // branch-free body; the last slab is peeled below
     const float* st = lds + stage * STAGE;
     stage = stage + 1 == STAGES ? 0 : stage + 1;
@@ -827,9 +842,11 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     __builtin_amdgcn_sched_barrier(0);
   }
   load(F1, lds + stage * STAGE, 1);
+  stage = stage + 1 == STAGES ? 0 : stage + 1;
   mma(F0);
   mma(F1);
   conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
+  }
 }
 
 template <int CM, int NP, int PREC, int STAGES>
@@ -845,7 +862,13 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
+  // TA_CONV_PERSIST=32 caps the grid at one workgroup per CU (32 per XCD), each walking several tiles: +3 % on a
+  // kernel that has the GPU to itself (next tile's first slabs stream under the epilogue), but -3 % end to end
+  // with three streams sharing the GPU, where short-lived workgroups let the other streams' kernels interleave.
+  // Default: one workgroup per tile.
+  static const int max_groups = getenv("TA_CONV_PERSIST") ? atoi(getenv("TA_CONV_PERSIST")) : (1 << 28);
+  const int launch_groups = groups < max_groups ? groups : max_groups;
+  hipLaunchKernelGGL(kern, dim3(launch_groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }
