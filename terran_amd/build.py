@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + headers):
             extra = ['-ffp-contract=off'] if src.endswith('_post.hip') else []   # bit-exact float steps
-            cmd = [hipcc] + FLAGS + extra + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + extra + os.environ.get('TA_EXTRA_FLAGS', '').split() + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

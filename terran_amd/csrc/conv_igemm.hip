@@ -26,6 +26,20 @@
 #include "act_format.h"
 #include "ta_internal.h"
 
+#ifdef TA_CONV_TRACE
+// Debug build only (TA_EXTRA_FLAGS=-DTA_CONV_TRACE): cycle stamps of workgroup 0 of the split kernel.
+__device__ long long ta_trace_buf[64];
+#define TA_STAMP(i)                                                              \
+  do {                                                                           \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) ta_trace_buf[(i)] = __builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int ta_debug_trace_read(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ta_trace_buf), sizeof(long long) * n);
+}
+#else
+#define TA_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -613,6 +627,170 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 }
 
 
+// Epilogue of the split-role kernel, staged through LDS.  Straight from the accumulators a store instruction
+// scatters 8-16 B to 32 different pixels (32 cache lines per instruction, 4-8x write amplification: measured 6.2 us
+// per tile, most of a launch's fixed cost).  Here the consumers first park the raw 128 x 128 (64 x 256) tile in LDS
+// as [pixel][cout] (16-byte chunks XOR-swizzled with the pixel row so the column-wise writes are conflict-free),
+// then every lane takes 8 consecutive channels of one pixel -- a wave instruction covers whole 128-byte lines --
+// and applies bias / ReLU / PReLU / residual / second affine output on the way out.
+struct ta_f32x8 {
+  f32x4 a, b;             // channels ch..ch+3, ch+4..ch+7
+};
+__device__ __forceinline__ ta_f32x8 ta_ld8(const float* pix, int ch, int fmt) {      // ch % 8 == 0
+  ta_f32x8 r;
+  if (fmt == TA_FMT_F32) {
+    r.a = *(const f32x4*)(pix + ch);
+    r.b = *(const f32x4*)(pix + ch + 4);
+    return r;
+  }
+  const char* q = (const char*)pix + ((ch >> 5) << 7) + ((ch & 31) << 1);
+  const uint4 h = *(const uint4*)q, l = *(const uint4*)(q + 64);
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16);
+    v[2 * i + 1] = __uint_as_float(hw[i] & 0xFFFF0000u) + __uint_as_float(lw[i] & 0xFFFF0000u);
+  }
+  r.a = f32x4{v[0], v[1], v[2], v[3]};
+  r.b = f32x4{v[4], v[5], v[6], v[7]};
+  return r;
+}
+__device__ __forceinline__ void ta_st8(float* pix, int ch, int fmt, const ta_f32x8& v) {   // ch % 8 == 0
+  if (fmt == TA_FMT_F32) {
+    *(f32x4*)(pix + ch) = v.a;
+    *(f32x4*)(pix + ch + 4) = v.b;
+    return;
+  }
+  // two floats per v_cvt_pk_bf16_f32 (round to nearest even, same as the scalar conversion)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const float x[8] = {v.a[0], v.a[1], v.a[2], v.a[3], v.b[0], v.b[1], v.b[2], v.b[3]};
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2 h = __builtin_convertvector((f32x2){x[2 * i], x[2 * i + 1]}, bf16x2);
+    hw[i] = __builtin_bit_cast(unsigned, h);
+    const f32x2 r = {x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u)};
+    lw[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  }
+  char* q = (char*)pix + ((ch >> 5) << 7) + ((ch & 31) << 1);
+  *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+template <int BN>
+__device__ __forceinline__ void conv_epilogue_park(f32x16 (&acc)[2][2], float* lds, int cm, int cn, int lane) {
+  constexpr int NCH = BN / 4;                      // 16-byte chunks per pixel row of the staged tile
+  // ---- phase 1: accumulators -> LDS [pixel][cout]; acc[a][b][r]: pixel = lane & 31, cout = 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int row = cn * 64 + b * 32 + (lane & 31);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (cm * 64 + a * 32 + 8 * j + 4 * (lane >> 5)) >> 2;
+        *(f32x4*)(lds + (row * NCH + (c ^ (row & (NCH - 1)))) * 4) =
+            f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+      }
+  }
+}
+
+// ---- phase 2 (all NT threads of the workgroup, producers included): lane = (pixel row, 8 consecutive channels)
+template <int BN, int BM, int NT>
+__device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid,
+                                                    int HoWo) {
+  constexpr int NCH = BN / 4;
+  constexpr int G = BN / 8;                        // 8-channel groups per pixel
+  constexpr int RPI = NT / G;                      // pixel rows per pass of the workgroup
+  const int k8 = tid % G, r0 = tid / G;
+  const int co = ct0 + 8 * k8;
+  const int n4 = p.cout - co >= 8 ? 2 : (p.cout - co >= 4 ? 1 : 0);    // valid 4-channel halves (cout % 4 == 0)
+  if (n4 == 0) return;
+  const f32x4 bias0 = *(const f32x4*)(p.bias + co), bias1 = *(const f32x4*)(p.bias + co + 4);   // padded to coutp
+  f32x4 sl0 = {0, 0, 0, 0}, sl1 = {0, 0, 0, 0}, sc0 = sl0, sc1 = sl0, sh0 = sl0, sh1 = sl0;
+  if (p.act == TA_ACT_PRELU) {
+    sl0 = *(const f32x4*)(p.prelu + co);
+    sl1 = *(const f32x4*)(p.prelu + co + 4);
+  }
+  if (p.out2) {
+    sc0 = *(const f32x4*)(p.scale2 + co);
+    sc1 = *(const f32x4*)(p.scale2 + co + 4);
+    sh0 = *(const f32x4*)(p.shift2 + co);
+    sh1 = *(const f32x4*)(p.shift2 + co + 4);
+  }
+  int pix = pt0 + r0;
+  int img = pix / HoWo;
+  int rem = pix - img * HoWo;
+  int y = rem / p.Wo;
+  int x = rem - y * p.Wo;
+#pragma unroll 2
+  for (int row = r0; row < BM; row += RPI, pix += RPI) {
+    if (pix >= p.M) break;
+    const int sw = row & (NCH - 1);
+    ta_f32x8 v;
+    v.a = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
+    v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v.a[e] += bias0[e];
+      v.b[e] += bias1[e];
+    }
+    if (p.act == TA_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] = v.a[e] > 0.f ? v.a[e] : 0.f;
+        v.b[e] = v.b[e] > 0.f ? v.b[e] : 0.f;
+      }
+    } else if (p.act == TA_ACT_PRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] = v.a[e] > 0.f ? v.a[e] : v.a[e] * sl0[e];
+        v.b[e] = v.b[e] > 0.f ? v.b[e] : v.b[e] * sl1[e];
+      }
+    }
+    if (p.res) {
+      const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
+      const float* rs = p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0;
+      if (n4 == 2) {
+        const ta_f32x8 r = ta_ld8(rs, p.res_ch + co, p.res_fmt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v.a[e] += r.a[e];
+          v.b[e] += r.b[e];
+        }
+      } else {
+        const f32x4 r = ta_ld4(rs, p.res_ch + co, p.res_fmt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v.a[e] += r[e];
+      }
+    }
+    float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
+    if (n4 == 2) ta_st8(o, p.out_ch + co, p.out_fmt, v);
+    else ta_st4(o, p.out_ch + co, p.out_fmt, v.a);
+    if (p.out2) {
+      float* o2 = p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0;
+      ta_f32x8 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        z.a[e] = v.a[e] * sc0[e] + sh0[e];
+        z.b[e] = v.b[e] * sc1[e] + sh1[e];
+      }
+      if (n4 == 2) ta_st8(o2, p.o2_ch + co, p.o2_fmt, z);
+      else ta_st4(o2, p.o2_ch + co, p.o2_fmt, z.a);
+    }
+    x += RPI;                                        // next pass: RPI pixels further in raster order
+    while (x >= p.Wo) {
+      x -= p.Wo;
+      if (++y == p.Ho) {
+        y = 0;
+        ++img;
+      }
+    }
+  }
+}
+
 // ---- split-role kernel (f32 mode, or bf16 modes on pre-split activations; 128 x 128 or 64 x 256 tiles) --
 // Measured with tools/probe/*: the global -> LDS DMA path sustains at most ~34 B/clk/CU however many slabs are in
 // flight (24 with only 4 issuing waves), and MFMA issue is NOT slowed by DMA waves on the same SIMD -- but a wave
@@ -637,29 +815,27 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == 0) TA_STAMP(0);                       // kernel entry (consumer 0)
+  if (wave == 4) TA_STAMP(8);                       // kernel entry (producer 0)
 
-  // Persistent workgroups: block b (XCD b % 8) walks the tile groups b >> 3, + gridDim.x >> 3, ... of its XCD.
-  // The stage ring and the barrier protocol simply continue across tiles, so the producers stream the first slabs
-  // of the next tile while the consumers run the epilogue of the current one.
   const int n_ct = p.coutp / BN;
-  const int xcd = blockIdx.x & 7;
+  const int grp = blockIdx.x >> 3, xcd = blockIdx.x & 7;
   const int n_pt = (p.M + BM - 1) / BM;
-  const int n_grp = ((n_pt + 7) >> 3) * n_ct;
-  const int grp_step = gridDim.x >> 3;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
+  const int ct0 = (grp % n_ct) * BN;
+  const int pt0 = pt * BM;
   const int HoWo = p.Ho * p.Wo;
   const int S = p.n_slabs;
+  // LDS-staged, line-coalesced epilogue whenever every channel slice involved is 8-aligned
+  const bool lds_epilogue = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
 
   if (wave >= 4) {
     // ================= producer =================
     const int pw = wave - 4;
     const int pchunk = lane & 7;
     const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
-    int stage = 0;                                  // stage the next issued slab goes to (runs on across tiles)
-    for (int grp = blockIdx.x >> 3; grp < n_grp; grp += grp_step) {
-    const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
-    if (pt < 0) continue;
-    const int ct0 = (grp % n_ct) * BN;
-    const int pt0 = pt * BM;
+    int stage = 0;                                  // stage the next issued slab goes to
     // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR): the saddr form of global_load_lds
     const char* a_base = (const char*)p.w;
     unsigned a_off[QA > 0 ? QA : 1];
@@ -711,12 +887,14 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
         }
       }
     };
+    if (wave == 4) TA_STAMP(9);                     // producer: addresses ready
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
       if (i < S) {
         issue(i, stage);
         stage = stage + 1 == STAGES ? 0 : stage + 1;
       }
+    if (wave == 4) TA_STAMP(10);                    // producer: first slabs issued
     for (int s = 0; s < S; ++s) {
       const int rem = S - 1 - s;                    // slabs younger than s already issued: min(rem, STAGES-2)
       if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
@@ -729,18 +907,18 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
         stage = stage + 1 == STAGES ? 0 : stage + 1;
       }
     }
+    if (lds_epilogue) {                             // help drain the parked tile: twice the lanes for the epilogue math
+      __builtin_amdgcn_s_barrier();                 // E0
+      __builtin_amdgcn_s_barrier();                 // E1
+      asm volatile("" ::: "memory");
+      conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo);
     }
     return;
   }
 
   // ================= consumer =================
   const int cm = wave / CN, cn = wave % CN;
-  int stage = 0;                                    // stage of the slab being consumed (runs on across tiles)
-  for (int grp = blockIdx.x >> 3; grp < n_grp; grp += grp_step) {
-  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
-  if (pt < 0) continue;
-  const int ct0 = (grp % n_ct) * BN;
-  const int pt0 = pt * BM;
+  int stage = 0;                                    // stage of the slab being consumed
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -822,8 +1000,10 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     __builtin_amdgcn_sched_group_barrier(0x008, NMMA - NREAD, 0);
   };
   Frag F0, F1;
+  if (wave == 0) TA_STAMP(1);                       // consumer: set up, waiting for slab 0
   __builtin_amdgcn_s_barrier();                     // B_0: slab 0 visible
   asm volatile("" ::: "memory");
+  if (wave == 0) TA_STAMP(2);                       // consumer: slab 0 landed
   load(F0, lds + stage * STAGE, 0);
   for (int s = 0; s + 1 < S; ++s) {                 // branch-free body; the last slab is peeled below
     const float* st = lds + stage * STAGE;
@@ -845,8 +1025,18 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   stage = stage + 1 == STAGES ? 0 : stage + 1;
   mma(F0);
   mma(F1);
-  conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
+  if (wave == 0) TA_STAMP(3);                       // consumer: main loop done (last MFMAs issued)
+  if (lds_epilogue) {
+    __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: the ring can be reused
+    asm volatile("" ::: "memory");
+    conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
+    __builtin_amdgcn_s_barrier();                   // E1: tile parked
+    asm volatile("" ::: "memory");
+    conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo);
+  } else {
+    conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
   }
+  if (wave == 0) TA_STAMP(4);                       // consumer: epilogue stores issued
 }
 
 template <int CM, int NP, int PREC, int STAGES>
@@ -862,13 +1052,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  // TA_CONV_PERSIST=32 caps the grid at one workgroup per CU (32 per XCD), each walking several tiles: +3 % on a
-  // kernel that has the GPU to itself (next tile's first slabs stream under the epilogue), but -3 % end to end
-  // with three streams sharing the GPU, where short-lived workgroups let the other streams' kernels interleave.
-  // Default: one workgroup per tile.
-  static const int max_groups = getenv("TA_CONV_PERSIST") ? atoi(getenv("TA_CONV_PERSIST")) : (1 << 28);
-  const int launch_groups = groups < max_groups ? groups : max_groups;
-  hipLaunchKernelGGL(kern, dim3(launch_groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }
@@ -942,8 +1126,11 @@ static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
   return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
 }
 
-int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
-  if (p.M <= 0) return TA_OK;
+int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
+  if (p_in.M <= 0) return TA_OK;
+  static const int direct = getenv("TA_CONV_DIRECT_EPILOGUE") ? 1 : 0;      // A/B switch: accumulators straight to global
+  ta_conv_launch p = p_in;
+  p.direct_epilogue = direct;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {

@@ -161,6 +161,7 @@ struct ta_conv_launch {
   int res_img, res_row, res_pix, res_off0, res_up2, res_ch, res_fmt;
   int o2_img, o2_row, o2_pix, o2_off0, o2_ch, o2_fmt;
   int in_fmt;
+  int direct_epilogue;                         // debug A/B: 1 = split kernel stores straight from the accumulators
 };
 
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);

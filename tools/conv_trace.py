@@ -1,0 +1,36 @@
+"""Cycle stamps inside one workgroup of the split-role conv kernel (debug build: TA_EXTRA_FLAGS=-DTA_CONV_TRACE
+python -m terran_amd.build --force).  Prints where the fixed ~10 us of a launch go."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from terran_amd import lib, pack, synth   # noqa: E402
+
+ctx = lib.Context(0)
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rng = np.random.default_rng(0)
+P = pack.Program(pack.MODEL_OPENPOSE, 'bf16x3')
+t0 = P.tensor(4, 1)
+P.input_tensor = t0
+t1 = P.tensor(128, k // 2)
+P.conv(t0, t1, rng.normal(0, 0.3, (128, 3, 3, 3)).astype(np.float32), np.zeros(128, np.float32), act=pack.ACT_RELU)
+t2 = P.tensor(128, 0)
+P.conv(t1, t2, rng.normal(0, 0.05, (128, 128, k, k)).astype(np.float32), np.zeros(128, np.float32), act=pack.ACT_RELU)
+P.outputs = [t2]
+m = lib.Model(ctx, P)
+fr = ctx.upload(synth.frames(1, 32, 23, 40))
+for _ in range(3):
+    m.forward_frames(fr)
+ctx.sync()
+buf = (C.c_longlong * 16)()
+ctx.lib.ta_debug_trace_read.argtypes = [C.c_void_p, C.c_int]
+assert ctx.lib.ta_debug_trace_read(buf, 16) == 0
+t = list(buf)
+base = min(t[0], t[8])
+names = {0: 'consumer entry', 1: 'consumer set up (waits B_0)', 2: 'slab 0 landed', 3: 'main loop done', 4: 'epilogue issued',
+         8: 'producer entry', 9: 'producer addresses ready', 10: 'first slabs issued'}
+for i in (8, 9, 10, 0, 1, 2, 3, 4):
+    print('%-32s +%7d cycles' % (names[i], t[i] - base))
