@@ -627,6 +627,41 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 }
 
 
+// (img, y, x) of the pixels pt0 + d of a tile, without a full integer division per lane: the tile's first pixel is
+// decomposed once (wave-uniform), every other pixel is d < 65536 further in raster order, so its carries are small
+// quotients that an f32 multiply by the reciprocal gets right to +-1 (fixed up exactly).
+struct ta_pixel_walk {
+  int img0, y0, x0, Wo, Ho;
+  float rWo, rHo;
+  __device__ __forceinline__ ta_pixel_walk(const ta_conv_launch& p, int pt0, int HoWo) {
+    img0 = pt0 / HoWo;
+    const int rem = pt0 - img0 * HoWo;
+    y0 = rem / p.Wo;
+    x0 = rem - y0 * p.Wo;
+    Wo = p.Wo;
+    Ho = p.Ho;
+    rWo = 1.0f / (float)p.Wo;
+    rHo = 1.0f / (float)p.Ho;
+  }
+  static __device__ __forceinline__ void divmod(int t, int d, float rd, int& q, int& r) {
+    q = (int)((float)t * rd);
+    r = t - q * d;
+    if (r < 0) {
+      --q;
+      r += d;
+    } else if (r >= d) {
+      ++q;
+      r -= d;
+    }
+  }
+  __device__ __forceinline__ void at(int d, int& img, int& y, int& x) const {
+    int qy, qi;
+    divmod(x0 + d, Wo, rWo, qy, x);
+    divmod(y0 + qy, Ho, rHo, qi, y);
+    img = img0 + qi;
+  }
+};
+
 // Epilogue of the split-role kernel, staged through LDS.  Straight from the accumulators a store instruction
 // scatters 8-16 B to 32 different pixels (32 cache lines per instruction, 4-8x write amplification: measured 6.2 us
 // per tile, most of a launch's fixed cost).  Here the consumers first park the raw 128 x 128 (64 x 256) tile in LDS
@@ -721,10 +756,8 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     sh1 = *(const f32x4*)(p.shift2 + co + 4);
   }
   int pix = pt0 + r0;
-  int img = pix / HoWo;
-  int rem = pix - img * HoWo;
-  int y = rem / p.Wo;
-  int x = rem - y * p.Wo;
+  int img, y, x;
+  ta_pixel_walk(p, pt0, HoWo).at(r0, img, y, x);
 #pragma unroll 2
   for (int row = r0; row < BM; row += RPI, pix += RPI) {
     if (pix >= p.M) break;
@@ -804,6 +837,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
 template <int CM, int NP, int PREC, int STAGES>
 __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_split(const ta_conv_launch p) {
   static_assert(NP == 4 || NP == 8, "4 or 8 producer waves");
+  static_assert(STAGES == 3, "the producer's issue order and waits are written for a 3-stage ring");
   static_assert(CM == 1 || CM == 2, "consumer grid 1x4 (64 cout x 256 px) or 2x2 (128 x 128)");
   constexpr int CN = 4 / CM;
   constexpr int BN = CM * 64, BM = CN * 64;
@@ -835,47 +869,39 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     const int pw = wave - 4;
     const int pchunk = lane & 7;
     const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
-    int stage = 0;                                  // stage the next issued slab goes to
     // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR): the saddr form of global_load_lds
     const char* a_base = (const char*)p.w;
-    unsigned a_off[QA > 0 ? QA : 1];
+    const size_t a_slab_bytes = (size_t)p.coutp * 128;
+    unsigned a_off[QA];
     unsigned b_off[NI - QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) a_off[q] = (unsigned)(((ct0 + (q * NP + pw) * 8 + (lane >> 3)) * 32 + lchunk * 4) * 4);
+    auto issue_a = [&](int s, int stage) {
+#pragma unroll
+      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)s * a_slab_bytes, a_off[q], lds + stage * STAGE + (q * NP + pw) * 256);
+    };
+    // the weight rows of the first two slabs need no pixel arithmetic: get them moving first
+    issue_a(0, 0);
+    if (S > 1) issue_a(1, 1);
     // pixel rows: offsets relative to the tile's first pixel (pixels of a tile ascend in raster order)
-    const int img0 = pt0 / HoWo;
-    const int rem0 = pt0 - img0 * HoWo;
-    const int y0 = rem0 / p.Wo, x0 = rem0 - y0 * p.Wo;
-    const size_t off0 = (size_t)img0 * p.in_img + (size_t)(y0 * p.stride) * p.in_row + (size_t)(x0 * p.stride) * p.in_pix +
-                        p.in_off0 + p.in_ch_off;
+    const ta_pixel_walk walk(p, pt0, HoWo);
+    const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)(walk.y0 * p.stride) * p.in_row +
+                        (size_t)(walk.x0 * p.stride) * p.in_pix + p.in_off0 + p.in_ch_off;
     const char* b_base = (const char*)(p.in + off0);
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const int row = (q * NP + pw) * 8 + (lane >> 3);      // row of the stage image: [BN weight rows | BM pixel rows]
-      if (q < QA) {
-        a_off[q] = (unsigned)(((ct0 + row) * 32 + lchunk * 4) * 4);
-      } else {
-        int pix = pt0 + row - BN;
-        if (pix >= p.M) pix = pt0;
-        const int img = pix / HoWo;
-        const int rem = pix - img * HoWo;
-        const int y = rem / p.Wo;
-        const int x = rem - y * p.Wo;
-        const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row +
-                           (size_t)(x * p.stride) * p.in_pix + p.in_off0 + p.in_ch_off;
-        b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
-      }
+    for (int q = QA; q < NI; ++q) {
+      const int d = (q * NP + pw) * 8 + (lane >> 3) - BN;   // pixel row of the stage image
+      int img, y, x;
+      walk.at(pt0 + d < p.M ? d : 0, img, y, x);
+      const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row + (size_t)(x * p.stride) * p.in_pix +
+                         p.in_off0 + p.in_ch_off;
+      b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
     }
-    const size_t a_slab_bytes = (size_t)p.coutp * 128;
     int k_cb = 0, k_x = 0, k_off = 0;
     const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
-    auto issue = [&](int s, int stage) {
-      float* base = lds + stage * STAGE;
-      const char* ua = a_base + (size_t)s * a_slab_bytes;
-      const char* ub = b_base + k_off;
+    auto issue_b = [&](int stage) {                 // pixel rows of the next slab in K order
 #pragma unroll
-      for (int q = 0; q < NI; ++q) {
-        const int t = q * NP + pw;
-        ta_dma16(q < QA ? ua : ub, q < QA ? a_off[q < QA ? q : 0] : b_off[q < QA ? 0 : q - QA], base + t * 256);
-      }
+      for (int q = QA; q < NI; ++q) ta_dma16(b_base + k_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
       ++k_cb;
       k_off += 128;
       if (k_cb == p.k_cblocks) {
@@ -888,23 +914,21 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
       }
     };
     if (wave == 4) TA_STAMP(9);                     // producer: addresses ready
-#pragma unroll
-    for (int i = 0; i < STAGES - 1; ++i)
-      if (i < S) {
-        issue(i, stage);
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
-      }
+    issue_b(0);
+    if (S > 1) issue_b(1);
     if (wave == 4) TA_STAMP(10);                    // producer: first slabs issued
+    int stage = 2;                                  // stage the next issued slab goes to
     for (int s = 0; s < S; ++s) {
-      const int rem = S - 1 - s;                    // slabs younger than s already issued: min(rem, STAGES-2)
-      if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
-      else if (STAGES == 4 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      // slab s must have landed; issue order was [A0 A1 B0 B1] then [A B] per slab, and vmcnt counts in issue order
+      if (s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - QA) : "memory");
+      else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // B_s: slab s landed (all producers); consumers have drained slab s-1
       asm volatile("" ::: "memory");
-      if (s + STAGES - 1 < S) {
-        issue(s + STAGES - 1, stage);
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
+      if (s + 2 < S) {
+        issue_a(s + 2, stage);
+        issue_b(stage);
+        stage = stage == 2 ? 0 : stage + 1;
       }
     }
     if (lds_epilogue) {                             // help drain the parked tile: twice the lanes for the epilogue math
@@ -1099,14 +1123,12 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
 template <int PREC>
 static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
   // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles,
-  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31..33 = split-role variants)
+  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31 = split-role kernel with 8 producer waves)
   static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
   if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
     if constexpr (PREC != PREC_F32) {
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 128 == 0 && cfg != 1) {
         if (cfg == 31) return launch_split<2, 8, PREC, 3>(ctx, p);
-        if (cfg == 32) return launch_split<2, 8, PREC, 4>(ctx, p);
-        if (cfg == 33) return launch_split<2, 4, PREC, 4>(ctx, p);
         return launch_split<2, 4, PREC, 3>(ctx, p);
       }
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, PREC, 3>(ctx, p);
