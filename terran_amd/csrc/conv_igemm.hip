@@ -735,12 +735,22 @@ __device__ __forceinline__ void conv_epilogue_park(f32x16 (&acc)[2][2], float* l
 // ---- phase 2 (all NT threads of the workgroup, producers included): lane = (pixel row, 8 consecutive channels)
 template <int BN, int BM, int NT>
 __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid,
-                                                    int HoWo) {
+                                                    int HoWo, int ks) {
   constexpr int NCH = BN / 4;
   constexpr int G = BN / 8;                        // 8-channel groups per pixel
   constexpr int RPI = NT / G;                      // pixel rows per pass of the workgroup
   const int k8 = tid % G, r0 = tid / G;
   const int co = ct0 + 8 * k8;
+  if (p.k_split > 1) {                             // K-split: raw sums of this K range -> partial[ks][pixel][coutp]
+    float* dst = p.partial + (size_t)ks * p.M * p.coutp + co;
+    for (int row = r0; row < BM && pt0 + row < p.M; row += RPI) {
+      const int sw = row & (NCH - 1);
+      float* o = dst + (size_t)(pt0 + row) * p.coutp;
+      *(f32x4*)o = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
+      *(f32x4*)(o + 4) = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+    }
+    return;
+  }
   const int n4 = p.cout - co >= 8 ? 2 : (p.cout - co >= 4 ? 1 : 0);    // valid 4-channel halves (cout % 4 == 0)
   if (n4 == 0) return;
   const f32x4 bias0 = *(const f32x4*)(p.bias + co), bias1 = *(const f32x4*)(p.bias + co + 4);   // padded to coutp
@@ -853,16 +863,21 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   if (wave == 4) TA_STAMP(8);                       // kernel entry (producer 0)
 
   const int n_ct = p.coutp / BN;
-  const int grp = blockIdx.x >> 3, xcd = blockIdx.x & 7;
   const int n_pt = (p.M + BM - 1) / BM;
+  const int tile_blocks = (((n_pt + 7) >> 3) * n_ct) << 3;      // blocks per K range
+  const int ks = blockIdx.x / tile_blocks;                       // K range of this workgroup (0 unless K-split)
+  const int bid = blockIdx.x - ks * tile_blocks;
+  const int grp = bid >> 3, xcd = bid & 7;
   const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
   if (pt < 0) return;
   const int ct0 = (grp % n_ct) * BN;
   const int pt0 = pt * BM;
   const int HoWo = p.Ho * p.Wo;
-  const int S = p.n_slabs;
-  // LDS-staged, line-coalesced epilogue whenever every channel slice involved is 8-aligned
-  const bool lds_epilogue = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
+  const int s_begin = (int)(((long long)ks * p.n_slabs) / p.k_split);
+  const int S = (int)(((long long)(ks + 1) * p.n_slabs) / p.k_split) - s_begin;
+  // LDS-staged, line-coalesced epilogue whenever every channel slice involved is 8-aligned (always when K-split:
+  // the raw sums go to the workspace)
+  const bool lds_epilogue = p.k_split > 1 || (((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0);
 
   if (wave >= 4) {
     // ================= producer =================
@@ -878,7 +893,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     for (int q = 0; q < QA; ++q) a_off[q] = (unsigned)(((ct0 + (q * NP + pw) * 8 + (lane >> 3)) * 32 + lchunk * 4) * 4);
     auto issue_a = [&](int s, int stage) {
 #pragma unroll
-      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)s * a_slab_bytes, a_off[q], lds + stage * STAGE + (q * NP + pw) * 256);
+      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)(s_begin + s) * a_slab_bytes, a_off[q], lds + stage * STAGE + (q * NP + pw) * 256);
     };
     // the weight rows of the first two slabs need no pixel arithmetic: get them moving first
     issue_a(0, 0);
@@ -897,8 +912,10 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
                          p.in_off0 + p.in_ch_off;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
     }
-    int k_cb = 0, k_x = 0, k_off = 0;
     const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
+    int k_cb = s_begin % p.k_cblocks;               // K walk starts at slab s_begin: (channel block, kx, ky)
+    int k_x = (s_begin / p.k_cblocks) % p.k_w;
+    int k_off = k_cb * 128 + k_x * pix_bytes + (s_begin / p.k_cblocks / p.k_w) * row_bytes;
     auto issue_b = [&](int stage) {                 // pixel rows of the next slab in K order
 #pragma unroll
       for (int q = QA; q < NI; ++q) ta_dma16(b_base + k_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
       __builtin_amdgcn_s_barrier();                 // E0
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
-      conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo);
+      conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
   }
@@ -1056,11 +1073,40 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
-    conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo);
+    conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
   }
   if (wave == 0) TA_STAMP(4);                       // consumer: epilogue stores issued
+}
+
+// Second pass of a K-split conv: out = act(sum_k partial[k] + bias), ranges added in ascending order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch p) {
+  const int c4 = p.cout >> 2;
+  const int total = p.M * c4;
+  const int HoWo = p.Ho * p.Wo;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int pix = i / c4, co = (i - pix * c4) * 4;
+    f32x4 v = *(const f32x4*)(p.bias + co);
+    for (int k = 0; k < p.k_split; ++k) {
+      const f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * p.M + pix) * p.coutp + co);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t[e];
+    }
+    if (p.act == TA_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (p.act == TA_ACT_PRELU) {
+      const f32x4 sl = *(const f32x4*)(p.prelu + co);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
+    }
+    const int img = pix / HoWo;
+    const int rem = pix - img * HoWo;
+    const int y = rem / p.Wo, x = rem - y * p.Wo;
+    ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, p.out_ch + co,
+           p.out_fmt, v);
+  }
 }
 
 template <int CM, int NP, int PREC, int STAGES>
@@ -1076,8 +1122,13 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
+  hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
+  if (p.k_split > 1) {
+    const int total = p.M * (p.cout >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, p);
+    TA_HIP(ctx, hipGetLastError());
+  }
   return TA_OK;
 }
 
@@ -1153,6 +1204,10 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   static const int direct = getenv("TA_CONV_DIRECT_EPILOGUE") ? 1 : 0;      // A/B switch: accumulators straight to global
   ta_conv_launch p = p_in;
   p.direct_epilogue = direct;
+  if (p.k_split < 1 || !p.partial) p.k_split = 1;
+  static const int no_ksplit = getenv("TA_CONV_NO_KSPLIT") ? 1 : 0;            // A/B switch
+  static const int cfg_env = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
+  if (no_ksplit || cfg_env == 1 || cfg_env == 2 || cfg_env == 9) p.k_split = 1;    // only the split-role kernel knows K ranges
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {

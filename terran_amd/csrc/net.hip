@@ -8,10 +8,20 @@
 // the context's stream.
 #include <string.h>
 
+#include <algorithm>
+
 #include "act_format.h"
 #include "ta_internal.h"
 
 static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+// A conv may be K-split when it runs on the split-role kernel (uniform K walk; f32 operands in f32 mode, pre-split
+// operands in the bf16 modes) and its epilogue is plain (no residual, no second output).
+static bool conv_ksplit_eligible(const ta_op_desc& op, int in_fmt) {
+  const bool uniform = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
+  const bool kernel_ok = op.prec == 0 ? in_fmt == TA_FMT_F32 : in_fmt == TA_FMT_SPLIT;
+  return uniform && kernel_ok && op.res < 0 && op.out2 < 0;
+}
 
 #define TA_MAX_PLANS 4
 #define TA_MAX_PLAN_BYTES ((size_t)96 << 30)
@@ -32,6 +42,7 @@ static void activate(ta_model* m, ta_plan* pl) {
   m->tensors = pl->tensors;
   m->ktab_dev = pl->ktab_dev;
   m->ktab_off = pl->ktab_off;
+  m->splitk_ws = pl->splitk_ws;
 }
 
 static void free_plans(ta_model* m) {
@@ -153,6 +164,17 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     offs[i] = total;
     total += (bytes + 255) & ~(size_t)255;
   }
+  // workspace of the K-split convs (see ta_conv_ksplit): the largest partial[k][pixel][coutp] any op needs
+  size_t ws_bytes = 0;
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const ta_op_desc& op = m->ops[oi];
+    if (op.type != TA_OP_CONV) continue;
+    const int M = ts[op.out].n * ts[op.out].h * ts[op.out].w;
+    const int ks = ta_conv_ksplit(op.coutp, op.n_slabs, conv_ksplit_eligible(op, ts[op.in].fmt));
+    if (ks > 1) ws_bytes = std::max(ws_bytes, (size_t)ks * M * op.coutp * sizeof(float));
+  }
+  const size_t ws_off = total;
+  total += (ws_bytes + 255) & ~(size_t)255;
   hipError_t e = hipMalloc((void**)&np->arena, total ? total : 256);
   if (e != hipSuccess) return ta_fail(ctx, TA_E_DEVICE, "plan: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
   np->arena_bytes = total;
@@ -161,6 +183,7 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     if (set[i] && ts[i].owns) ts[i].dev = (float*)(np->arena + offs[i]);
   for (int i = 0; i < T; ++i)
     if (set[i] && !ts[i].owns) ts[i].dev = ts[m->tdesc[i].alias_of].dev;
+  np->splitk_ws = ws_bytes ? (float*)(np->arena + ws_off) : nullptr;
 
   // K-offset tables
   std::vector<int32_t> ktab;
@@ -262,6 +285,8 @@ int ta_model_run_ops(ta_model* m) {
           p.o2_ch = op.out2_ch_off;
           p.o2_fmt = t2.fmt;
         }
+        p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt)) : 1;
+        p.partial = m->splitk_ws;
         TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
         break;
       }

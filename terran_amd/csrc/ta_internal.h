@@ -162,7 +162,19 @@ struct ta_conv_launch {
   int o2_img, o2_row, o2_pix, o2_off0, o2_ch, o2_fmt;
   int in_fmt;
   int direct_epilogue;                         // debug A/B: 1 = split kernel stores straight from the accumulators
+  int k_split;                                 // > 1: K is cut in k_split ranges, one workgroup each; raw sums go to
+  float* partial;                              //      partial[k][pixel][coutp] and splitk_reduce_kernel finishes the op
 };
+
+// K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
+// 128 x 128 at the batch sizes in use): K is cut in a FIXED number of ranges that depends on the layer only, never on
+// the batch -- the summation order, and with it every output bit, must not change with the batch composition
+// (sharding a batch over GPUs has to reproduce the unsharded result exactly).  Shared by the planner (workspace size)
+// and the launcher.  1 = no split.
+static inline int ta_conv_ksplit(int coutp, int n_slabs, bool eligible) {
+  if (!eligible || coutp % 128 || n_slabs < 512) return 1;
+  return 32;
+}
 
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);
 
@@ -194,6 +206,7 @@ struct ta_plan {
   size_t arena_bytes = 0;
   int32_t* ktab_dev = nullptr;
   std::vector<size_t> ktab_off;   // per op, element offset into ktab_dev
+  float* splitk_ws = nullptr;     // workspace for K-split partial sums (inside the arena)
   uint64_t last_use = 0;
 };
 
@@ -213,6 +226,7 @@ struct ta_model {
   std::vector<ta_tensor> tensors;
   int32_t* ktab_dev = nullptr;
   std::vector<size_t> ktab_off;
+  float* splitk_ws = nullptr;
 };
 
 int ta_model_plan(ta_model* m, int n, int h, int w);
