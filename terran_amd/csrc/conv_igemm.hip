@@ -844,12 +844,12 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
 // the 64 x 128 kernel above).  One s_barrier per slab hands a landed slab to the consumers and a drained stage back
 // to the producers.  The consumer loop is software-pipelined at k-step (16) granularity with the barrier in the
 // middle, so both fragment reads of a slab hide under 12 MFMAs each and only two 8-fragment sets are live.
-template <int CM, int NP, int PREC, int STAGES>
-__global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_split(const ta_conv_launch p) {
+template <int CM, int CN, int NP, int PREC, int STAGES>
+__global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_igemm_split(const ta_conv_launch p) {
   static_assert(NP == 4 || NP == 8, "4 or 8 producer waves");
   static_assert(STAGES == 3, "the producer's issue order and waits are written for a 3-stage ring");
-  static_assert(CM == 1 || CM == 2, "consumer grid 1x4 (64 cout x 256 px) or 2x2 (128 x 128)");
-  constexpr int CN = 4 / CM;
+  static_assert(CM * CN == 4 || CM * CN == 8, "consumer grid: 1x4 (64 cout x 256 px), 2x2 (128 x 128) or 2x4 (128 x 256)");
+  constexpr int NC = CM * CN;                    // consumer waves (the first NC waves of the workgroup)
   constexpr int BN = CM * 64, BM = CN * 64;
   constexpr int NI = (BN + BM) / 8 / NP;         // DMA instructions per producer wave per slab
   constexpr int QA = BN / 8 / NP;                // ... of which weight rows
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave == 0) TA_STAMP(0);                       // kernel entry (consumer 0)
-  if (wave == 4) TA_STAMP(8);                       // kernel entry (producer 0)
+  if (wave == NC) TA_STAMP(8);                      // kernel entry (producer 0)
 
   const int n_ct = p.coutp / BN;
   const int n_pt = (p.M + BM - 1) / BM;
@@ -879,9 +879,9 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
   // the raw sums go to the workspace)
   const bool lds_epilogue = p.k_split > 1 || (((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0);
 
-  if (wave >= 4) {
+  if (wave >= NC) {
     // ================= producer =================
-    const int pw = wave - 4;
+    const int pw = wave - NC;
     const int pchunk = lane & 7;
     const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
     // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR): the saddr form of global_load_lds
@@ -930,10 +930,10 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
         }
       }
     };
-    if (wave == 4) TA_STAMP(9);                     // producer: addresses ready
+    if (wave == NC) TA_STAMP(9);                    // producer: addresses ready
     issue_b(0);
     if (S > 1) issue_b(1);
-    if (wave == 4) TA_STAMP(10);                    // producer: first slabs issued
+    if (wave == NC) TA_STAMP(10);                    // producer: first slabs issued
     int stage = 2;                                  // stage the next issued slab goes to
     for (int s = 0; s < S; ++s) {
       // slab s must have landed; issue order was [A0 A1 B0 B1] then [A B] per slab, and vmcnt counts in issue order
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
       __builtin_amdgcn_s_barrier();                 // E0
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
-      conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
+      conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
   }
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 2 : 3) void conv_igemm_spl
     conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
-    conv_epilogue_drain<BN, BM, 64 * (4 + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
+    conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
   }
@@ -1109,20 +1109,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
   }
 }
 
-template <int CM, int NP, int PREC, int STAGES>
+template <int CM, int CN, int NP, int PREC, int STAGES>
 static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
-  constexpr int BN = CM * 64, BM = (4 / CM) * 64;
+  constexpr int BN = CM * 64, BM = CN * 64;
   const int n_ct = p.coutp / BN;
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
-  auto kern = conv_igemm_split<CM, NP, PREC, STAGES>;
+  auto kern = conv_igemm_split<CM, CN, NP, PREC, STAGES>;
   static bool attr_set = false;
   if (!attr_set) {
     TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (4 + NP)), lds_bytes, ctx->stream, p);
+  hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   if (p.k_split > 1) {
     const int total = p.M * (p.cout >> 2);
@@ -1174,21 +1174,31 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
 template <int PREC>
 static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
   // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles,
-  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31 = split-role kernel with 8 producer waves)
+  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31 = split-role kernel with 8 producer waves,
+  // 40 = 128x256 tiles wherever possible, 42 = never)
   static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
   if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
     if constexpr (PREC != PREC_F32) {
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 128 == 0 && cfg != 1) {
-        if (cfg == 31) return launch_split<2, 8, PREC, 3>(ctx, p);
-        return launch_split<2, 4, PREC, 3>(ctx, p);
+        if (cfg == 31) return launch_split<2, 2, 8, PREC, 3>(ctx, p);
+        if (cfg == 40) return launch_split<2, 4, 4, PREC, 3>(ctx, p);
+        if (cfg != 42 && p.k_split == 1) {
+          // 128 x 256 tiles (8 consumer waves) stream 25 % fewer DMA bytes per FLOP and measure ~8 % faster per tile
+          // pair, but a CU holds one workgroup either way: take them when they do not cost a round of the 256 CUs
+          const int n_ct = p.coutp / 128;
+          const int t1 = ((p.M + 127) / 128) * n_ct, t2 = ((p.M + 255) / 256) * n_ct;
+          const int r1 = (t1 + 255) / 256, r2 = (t2 + 255) / 256;
+          if (r2 * 184 < r1 * 100) return launch_split<2, 4, 4, PREC, 3>(ctx, p);
+        }
+        return launch_split<2, 2, 4, PREC, 3>(ctx, p);
       }
-      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, PREC, 3>(ctx, p);
+      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, 4, PREC, 3>(ctx, p);
       if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
     }
     if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
     if constexpr (PREC == PREC_F32) {
-      if (p.coutp % 128 == 0 && cfg != 1) return launch_split<2, 4, PREC, 3>(ctx, p);
-      if (p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, PREC, 3>(ctx, p);
+      if (p.coutp % 128 == 0 && cfg != 1) return launch_split<2, 2, 4, PREC, 3>(ctx, p);
+      if (p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, 4, PREC, 3>(ctx, p);
     }
     if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
     if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
