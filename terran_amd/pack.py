@@ -297,29 +297,32 @@ def pack_openpose(sd, precision='f32'):
     cat_pos = np.concatenate([OP_PAF + np.arange(38), OP_HM + np.arange(19), OP_FEAT + np.arange(128)])
     for st in range(1, 7):
         xin, xout = (X0, X1) if st % 2 == 1 else (X1, X0)
-        for br in (1, 2):
-            layers = arch.openpose_stage_layers(st, br)
-            cur = xin
-            for li, (name, cin, cout, k, relu) in enumerate(layers):
+        # The first conv of the PAF branch and of the heat-map branch read the same stage input with the same
+        # kernel size: one launch with their output channels side by side (128 | 128); each branch then goes on
+        # from its channel slice.  Per output channel the arithmetic is unchanged.
+        l1, l2 = arch.openpose_stage_layers(st, 1), arch.openpose_stage_layers(st, 2)
+        (n1, cin, c1, k, r1), (n2, cin2, c2, k2, r2) = l1[0], l2[0]
+        assert (cin, k, r1) == (cin2, k2, r2) and c1 == c2 == 128
+        W = np.concatenate([np.asarray(sd['model%d_%d.%s.weight' % (st, br, n)]) for br, n in ((1, n1), (2, n2))])
+        b = np.concatenate([np.asarray(sd['model%d_%d.%s.bias' % (st, br, n)]) for br, n in ((1, n1), (2, n2))])
+        kw = dict(ch_pos=cat_pos, cin_p=OP_XCH) if cin == 185 else dict(in_ch_off=OP_FEAT)   # stage 1: feature slice only
+        first = P.tensor(c1 + c2, l1[1][3] // 2)
+        P.conv(xin, first, W, b, act=ACT_RELU if r1 else ACT_NONE, **kw)
+        for br, layers in ((1, l1), (2, l2)):
+            cur, kw = first, dict(in_ch_off=(br - 1) * c1)
+            for li in range(1, len(layers)):
+                name, cin, cout, k, relu = layers[li]
                 key = 'model%d_%d.%s' % (st, br, name)
                 W, b = sd[key + '.weight'], sd[key + '.bias']
                 act = ACT_RELU if relu else ACT_NONE
-                last = li == len(layers) - 1
-                kw = {}
-                if cur == xin:
-                    if cin == 185:
-                        kw = dict(ch_pos=cat_pos, cin_p=OP_XCH)
-                    else:                       # stage 1 reads only the feature slice
-                        kw = dict(in_ch_off=OP_FEAT)
-                if last:
+                if li == len(layers) - 1:
                     off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
                     P.conv(cur, xout, W, b, act=act, out_ch_off=off, cout_p=cp, **kw)
                     P.tap('stage%d_%s' % (st, 'paf' if br == 1 else 'hm'), xout, off, cout)
                 else:
-                    nk = layers[li + 1][3]
-                    o = P.tensor(cout, nk // 2)
+                    o = P.tensor(cout, layers[li + 1][3] // 2)
                     P.conv(cur, o, W, b, act=act, **kw)
-                    cur = o
+                    cur, kw = o, {}
     P.outputs = [X0]
     P.tap('pafs', X0, OP_PAF, 38)
     P.tap('heatmaps', X0, OP_HM, 19)
