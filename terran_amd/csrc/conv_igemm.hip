@@ -900,8 +900,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     if (S > 1) issue_a(1, 1);
     // pixel rows: offsets relative to the tile's first pixel (pixels of a tile ascend in raster order)
     const ta_pixel_walk walk(p, pt0, HoWo);
+    const int in_ch = p.in_ch_off + (p.group_cout ? (ct0 / p.group_cout) * p.group_cin : 0);   // grouped conv: this tile's group
     const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)(walk.y0 * p.stride) * p.in_row +
-                        (size_t)(walk.x0 * p.stride) * p.in_pix + p.in_off0 + p.in_ch_off;
+                        (size_t)(walk.x0 * p.stride) * p.in_pix + p.in_off0 + in_ch;
     const char* b_base = (const char*)(p.in + off0);
 #pragma unroll
     for (int q = QA; q < NI; ++q) {
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       int img, y, x;
       walk.at(pt0 + d < p.M ? d : 0, img, y, x);
       const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row + (size_t)(x * p.stride) * p.in_pix +
-                         p.in_off0 + p.in_ch_off;
+                         p.in_off0 + in_ch;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
     }
     const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
@@ -1218,6 +1219,8 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   static const int no_ksplit = getenv("TA_CONV_NO_KSPLIT") ? 1 : 0;            // A/B switch
   static const int cfg_env = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
   if (no_ksplit || cfg_env == 1 || cfg_env == 2 || cfg_env == 9) p.k_split = 1;    // only the split-role kernel knows K ranges
+  if (p.group_cout && (cfg_env == 1 || cfg_env == 2 || cfg_env == 9))
+    return ta_fail(ctx, TA_E_INVALID, "conv: grouped convolutions need the split-role kernel (TA_CONV_CFG=%d)", cfg_env);
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {

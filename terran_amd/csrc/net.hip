@@ -20,7 +20,7 @@ static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad -
 static bool conv_ksplit_eligible(const ta_op_desc& op, int in_fmt) {
   const bool uniform = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
   const bool kernel_ok = op.prec == 0 ? in_fmt == TA_FMT_F32 : in_fmt == TA_FMT_SPLIT;
-  return uniform && kernel_ok && op.res < 0 && op.out2 < 0;
+  return uniform && kernel_ok && op.res < 0 && op.out2 < 0 && op.groups <= 1;
 }
 
 #define TA_MAX_PLANS 4
@@ -135,6 +135,14 @@ int ta_model_plan(ta_model* m, int n, int h, int w) {
     const ta_tensor& ti = ts[op.in];
     switch (op.type) {
       case TA_OP_CONV:
+        if (op.groups > 1) {   // runs on the split-role kernel only: uniform K walk, 128-channel tiles inside one group
+          const bool ok = op.cin % 32 == 0 && op.n_slabs == op.kh * op.kw * (op.cin / 32) && op.n_slabs >= 2 &&
+                          op.cout % op.groups == 0 && (op.cout / op.groups) % 128 == 0 && op.cout == op.coutp &&
+                          op.in_ch_off % 32 == 0 && op.in_ch_off + op.groups * op.cin <= ti.c &&
+                          (op.prec == 0 ? ti.fmt == TA_FMT_F32 : ti.fmt == TA_FMT_SPLIT);
+          if (!ok) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu: unsupported grouped convolution", oi);
+        }
+        [[fallthrough]];
       case TA_OP_DWCONV:
         if (ti.halo < op.pad) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu needs halo %d, tensor has %d", oi, op.pad, ti.halo);
         TA_TRY(set_out(op.out, conv_out(ti.h, op.kh, op.stride, op.pad), conv_out(ti.w, op.kw, op.stride, op.pad)));
@@ -285,6 +293,10 @@ int ta_model_run_ops(ta_model* m) {
           p.o2_ch = op.out2_ch_off;
           p.o2_fmt = t2.fmt;
         }
+        if (op.groups > 1) {
+          p.group_cout = op.cout / op.groups;
+          p.group_cin = op.cin;
+        }
         p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt)) : 1;
         p.partial = m->splitk_ws;
         TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
@@ -337,7 +349,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 1) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 2) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)

@@ -50,9 +50,14 @@ struct ta_op_desc {
   int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
   int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (f32-class), 2 = bf16 (throughput)
+  int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
+  int32_t reserved;
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
+
+static_assert(sizeof(ta_blob_header) == 128 && sizeof(ta_tensor_desc) == 16 && sizeof(ta_op_desc) == 136,
+              "blob layout is shared with terran_amd/pack.py (HEADER_DT / TENSOR_DT / OP_DT)");
 
 // ---------------------------------------------------------------------------------------------
 // Context
@@ -162,6 +167,7 @@ struct ta_conv_launch {
   int o2_img, o2_row, o2_pix, o2_off0, o2_ch, o2_fmt;
   int in_fmt;
   int direct_epilogue;                         // debug A/B: 1 = split kernel stores straight from the accumulators
+  int group_cout, group_cin;                   // grouped conv: output channels / input channels per group (0 = dense)
   int k_split;                                 // > 1: K is cut in k_split ranges, one workgroup each; raw sums go to
   float* partial;                              //      partial[k][pixel][coutp] and splitk_reduce_kernel finishes the op
 };

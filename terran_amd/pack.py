@@ -12,6 +12,8 @@ epilogue) are documented next to each builder.
 Blob layout mirrors `terran_amd/csrc/ta_internal.h` (ta_blob_header / ta_tensor_desc /
 ta_op_desc).
 """
+import os
+
 import numpy as np
 
 from . import arch
@@ -31,10 +33,11 @@ HEADER_DT = np.dtype({
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
 FMT_F32, FMT_SPLIT = 0, 1
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
-           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec']
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'reserved']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
-assert OP_DT.itemsize == 128 and TENSOR_DT.itemsize == 16
+assert OP_DT.itemsize == 136 and TENSOR_DT.itemsize == 16
+BLOB_VERSION = 2            # 2: ta_op_desc grew `groups` (grouped convs)
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
@@ -106,11 +109,16 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None):
+             scale2=None, shift2=None, groups=1):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
-        ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p)."""
+        ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
+        groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
+        [in_ch_off + g cin_g, + cin_g) and writes output channels [out_ch_off + g cout_g, + cout_g); cin_g a multiple
+        of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups)."""
         W = np.asarray(W, dtype=np.float64)
         cout, cin, kh, kw = W.shape
+        if groups > 1:
+            assert cout % groups == 0 and cin % 32 == 0 and (cout // groups) % 128 == 0 and ch_pos is None
         if pad is None:
             pad = kh // 2
         if cin_p is None:
@@ -139,7 +147,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
-                  w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, reserved=0, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -150,7 +158,7 @@ class Program:
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
-                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
@@ -158,7 +166,8 @@ class Program:
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
-                  prec=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=0.0)
+                  prec=0, groups=1, reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)
 
@@ -238,7 +247,7 @@ class Program:
         w_off = _rup(o_off + ops.nbytes, 256)
         outs = np.full(16, -1, np.int32)
         outs[:len(self.outputs)] = self.outputs
-        hdr[0] = (MAGIC, 1, self.kind, len(self.tensors), len(self.ops), self.input_tensor, len(self.outputs), outs,
+        hdr[0] = (MAGIC, BLOB_VERSION, self.kind, len(self.tensors), len(self.ops), self.input_tensor, len(self.outputs), outs,
                   t_off, o_off, w_off, self.wbytes)
         head = hdr.tobytes() + tens.tobytes() + ops.tobytes()
         return head + b'\0' * (w_off - len(head)) + b''.join(self.wchunks)
@@ -306,23 +315,35 @@ def pack_openpose(sd, precision='f32'):
         W = np.concatenate([np.asarray(sd['model%d_%d.%s.weight' % (st, br, n)]) for br, n in ((1, n1), (2, n2))])
         b = np.concatenate([np.asarray(sd['model%d_%d.%s.bias' % (st, br, n)]) for br, n in ((1, n1), (2, n2))])
         kw = dict(ch_pos=cat_pos, cin_p=OP_XCH) if cin == 185 else dict(in_ch_off=OP_FEAT)   # stage 1: feature slice only
-        first = P.tensor(c1 + c2, l1[1][3] // 2)
-        P.conv(xin, first, W, b, act=ACT_RELU if r1 else ACT_NONE, **kw)
-        for br, layers in ((1, l1), (2, l2)):
-            cur, kw = first, dict(in_ch_off=(br - 1) * c1)
-            for li in range(1, len(layers)):
-                name, cin, cout, k, relu = layers[li]
-                key = 'model%d_%d.%s' % (st, br, name)
-                W, b = sd[key + '.weight'], sd[key + '.bias']
-                act = ACT_RELU if relu else ACT_NONE
-                if li == len(layers) - 1:
-                    off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
-                    P.conv(cur, xout, W, b, act=act, out_ch_off=off, cout_p=cp, **kw)
-                    P.tap('stage%d_%s' % (st, 'paf' if br == 1 else 'hm'), xout, off, cout)
-                else:
-                    o = P.tensor(cout, layers[li + 1][3] // 2)
-                    P.conv(cur, o, W, b, act=act, **kw)
-                    cur, kw = o, {}
+        cur = P.tensor(c1 + c2, l1[1][3] // 2)
+        P.conv(xin, cur, W, b, act=ACT_RELU if r1 else ACT_NONE, **kw)
+        # The middle layers of the two branches have identical shapes (model.py:56-86): each pair runs as ONE grouped
+        # conv (groups=2) over the side-by-side 128 | 128 (or 512 | 512) channels -- twice the tiles per launch, which
+        # is what lets the 1080p-sized maps use the 128 x 256 tile, and half the launches.
+        grouped = not os.environ.get('TERRAN_AMD_NO_GROUPED')        # A/B switch: one conv per branch instead
+        for li in range(1, len(l1) - 1):
+            (na, cin, cout, k, relu), (nb, cin2, cout2, k2, relu2) = l1[li], l2[li]
+            if not grouped:
+                o = P.tensor(2 * cout, l1[li + 1][3] // 2)
+                for br, n in ((1, na), (2, nb)):
+                    key = 'model%d_%d.%s' % (st, br, n)
+                    P.conv(cur, o, sd[key + '.weight'], sd[key + '.bias'], act=ACT_RELU if relu else ACT_NONE,
+                           in_ch_off=(br - 1) * cin, out_ch_off=(br - 1) * cout)
+                cur = o
+                continue
+            assert (cin, cout, k, relu) == (cin2, cout2, k2, relu2) and cin % 32 == 0 and cout % 128 == 0
+            W = np.concatenate([np.asarray(sd['model%d_%d.%s.weight' % (st, br, n)]) for br, n in ((1, na), (2, nb))])
+            b = np.concatenate([np.asarray(sd['model%d_%d.%s.bias' % (st, br, n)]) for br, n in ((1, na), (2, nb))])
+            o = P.tensor(2 * cout, l1[li + 1][3] // 2)
+            P.conv(cur, o, W, b, act=ACT_RELU if relu else ACT_NONE, groups=2)
+            cur = o
+        for br, layers in ((1, l1), (2, l2)):          # output convs: different widths (38 / 19), own slices of xout
+            name, cin, cout, k, relu = layers[-1]
+            key = 'model%d_%d.%s' % (st, br, name)
+            off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
+            P.conv(cur, xout, sd[key + '.weight'], sd[key + '.bias'], act=ACT_RELU if relu else ACT_NONE,
+                   in_ch_off=(br - 1) * cin, out_ch_off=off, cout_p=cp)
+            P.tap('stage%d_%s' % (st, 'paf' if br == 1 else 'hm'), xout, off, cout)
     P.outputs = [X0]
     P.tap('pafs', X0, OP_PAF, 38)
     P.tap('heatmaps', X0, OP_HM, 19)

@@ -66,7 +66,7 @@ def packed_program(kind, state, precision):
     """Pack `state` for `kind`, going through the repack cache when the weights come from a checkpoint file.
 
     Cache key = checkpoint id + precision + size/mtime of the .pth (terran/checkpoint.py:118-150 layout):
-    `$TERRAN_HOME/checkpoints/<id>.<precision>.tam`.  Dict states (tests, bench) are packed directly."""
+    `$TERRAN_HOME/checkpoints/<id>.<precision>.<size>.<mtime>.v<blob version>.tam`.  Dict states (tests, bench) are packed directly."""
     from . import checkpoint, pack
     packer = getattr(pack, 'pack_%s' % kind)
     path = None
@@ -77,7 +77,8 @@ def packed_program(kind, state, precision):
     if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE'):
         return packer(resolve_state(kind, state), precision)
     st = os.stat(path)
-    cache = '%s.%s.%d.%d.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime))
+    cache = '%s.%s.%d.%d.v%d.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime),
+                                     pack.BLOB_VERSION)
     if os.path.exists(cache):
         try:
             return pack.Program.from_cache(cache)

@@ -35,6 +35,9 @@ CASES = [
     dict(c1=64, cout=64, k=3, act=2, res=True, out2=True),
     dict(c1=32, cout=32, k=1, act=1, res=True),
     dict(c1=256, cout=256, k=3, n=3, h=14, w=14),
+    dict(c1=256, cout=256, k=3, groups=2),
+    dict(c1=256, cout=256, k=7, halo=3, groups=2, n=3, h=23, w=40),
+    dict(c1=384, cout=256, k=1, groups=2, in_off=128, cin_used=256, act=1),
 ]
 
 
@@ -66,7 +69,8 @@ def test_conv(ctx, case, precision):
     W1 = rng.normal(0, 0.3, (c1, 3, 3, 3)).astype(np.float32)
     b1 = rng.normal(0, 0.1, c1).astype(np.float32)
     P.conv(t0, t1, W1, b1, act=pack.ACT_RELU)
-    W2 = rng.normal(0, 1.0 / np.sqrt(cin_used * k * k), (cout, cin_used, k, k)).astype(np.float32)
+    groups = case.get('groups', 1)
+    W2 = rng.normal(0, 1.0 / np.sqrt(cin_used // groups * k * k), (cout, cin_used // groups, k, k)).astype(np.float32)
     b2 = rng.normal(0, 0.1, cout).astype(np.float32)
     t2 = P.tensor(out_total, 0, name='out')
     kw = {}
@@ -87,7 +91,11 @@ def test_conv(ctx, case, precision):
         scale2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
         shift2 = rng.normal(0, 0.2, cout).astype(np.float32)
         kw.update(out2=t3, scale2=scale2, shift2=shift2)
-    P.conv(t1, t2, W2, b2, stride=stride, pad=padv, act=act, in_ch_off=in_off, cin_p=cin_used,
+    if groups > 1:
+        kw['groups'] = groups
+    else:
+        kw['cin_p'] = cin_used
+    P.conv(t1, t2, W2, b2, stride=stride, pad=padv, act=act, in_ch_off=in_off,
            out_ch_off=out_off, cout_p=case.get('cout_p'), **kw)
     P.outputs = [t2]
     m = lib.Model(ctx, P)
@@ -98,7 +106,7 @@ def test_conv(ctx, case, precision):
     mid = F.relu(F.conv2d(x, torch.from_numpy(W1), torch.from_numpy(b1), padding=1))
     np.testing.assert_allclose(m.read('mid'), mid.numpy(), rtol=tol, atol=tol)
     y = F.conv2d(mid[:, in_off:in_off + cin_used], torch.from_numpy(W2), torch.from_numpy(b2), stride=stride,
-                 padding=padv)
+                 padding=padv, groups=groups)
     if act == 1:
         y = F.relu(y)
     elif act == 2:

@@ -91,7 +91,7 @@ def test_pack_programs_are_well_formed(states):
         hdr = np.frombuffer(blob[:128], pack.HEADER_DT)[0]
         assert hdr['magic'] == pack.MAGIC and hdr['n_ops'] == len(P.ops)
         assert hdr['weights_off'] % 256 == 0 and hdr['weights_off'] + hdr['weights_bytes'] == len(blob)
-        ops = np.frombuffer(blob[hdr['ops_off']:hdr['ops_off'] + 128 * len(P.ops)], pack.OP_DT)
+        ops = np.frombuffer(blob[hdr['ops_off']:hdr['ops_off'] + pack.OP_DT.itemsize * len(P.ops)], pack.OP_DT)
         conv = ops[ops['type'] == pack.OP_CONV]
         assert np.all(conv['coutp'] % 32 == 0) and np.all(conv['cin'] % 4 == 0) and np.all(conv['n_slabs'] > 0)
     # algorithmic MACs match SURVEY.md Appendix A (conv + linear, per image / crop)
