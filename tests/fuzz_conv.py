@@ -19,6 +19,13 @@ def draw(rng):
     c1 = int(rng.choice([4, 8, 16, 24, 32, 64, 96, 128, 160, 192, 256]))
     cout = int(rng.choice([4, 8, 19, 20, 32, 38, 60, 64, 100, 128, 132, 192, 256, 320]))
     case = dict(c1=c1, cout=cout, k=k, n=int(rng.integers(1, 6)), h=int(rng.integers(1, 34)), w=int(rng.integers(1, 48)))
+    if rng.random() < 0.12:                      # grouped conv: 128-channel output tiles inside one group
+        case.update(c1=int(rng.choice([64, 256, 512])), cout=int(rng.choice([256, 512])), groups=2, act=int(rng.choice([0, 1, 2])))
+        if k == 7:
+            case['halo'] = 3
+        if k == 1 and case['c1'] == 64:          # one K slab per group: rejected by the planner (needs >= 2)
+            case['c1'] = 256
+        return case
     if k > 1 and rng.random() < 0.3:
         case['stride'] = 2
     elif k == 1 and rng.random() < 0.2:
