@@ -1,6 +1,6 @@
 """bench.py -- end-to-end 1080p detect + embed + pose throughput on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 30 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -43,8 +43,8 @@ DTYPES = {'f32': 'f32', 'bf16x3': 'f32 (activations/accumulators f32; products o
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
     ap.add_argument('--cpu-frames', type=int, default=16, help='frames in the bounded CPU-baseline sample')
