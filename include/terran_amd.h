@@ -75,6 +75,9 @@ int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, 
 int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out);
 int ta_frames_shape(const ta_frames* f, int* n, int* h, int* w);
 int ta_frames_download(const ta_frames* f, uint8_t* nhwc_rgb);
+/* Releases the handle.  The device buffer is parked in its context (a few recent sizes, bounded in bytes) and handed
+ * to the next batch of the same size: the steady state of a video loop performs no hipMalloc / hipFree (a hipFree
+ * waits for every stream of the process).  Parked buffers are freed with the context. */
 void ta_frames_free(ta_frames* f);
 /* cv2.resize(..., INTER_LINEAR) semantics on the device
  * (face/detection/__init__.py:33-38, pose/openpose/wrapper.py:106-111). */
