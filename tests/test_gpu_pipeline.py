@@ -387,3 +387,25 @@ def test_argument_and_shape_errors(det, arc, ctx):
         from terran_amd import RetinaFace
         RetinaFace(device='cpu', state={})
     assert arc.call([], []) == []
+
+
+def test_face_tracking_over_device_detection(states, precision):
+    """SORT on top of the device detector: the same frame repeated keeps every identity, output dicts are the
+    detector's plus 'track' (terran/tracking/face.py:429-473)."""
+    from terran_amd import Detection
+    from terran_amd import tracking as T
+    T.reset_track_ids()
+    det = Detection(short_side=128, device=0, state=states('retinaface'), precision=precision)
+    tracker = T.face_tracking(detector=det, max_age=2, min_hits=0)
+    frame = synth.frames(0, 1, 240, 320)[0]
+    batch = np.stack([frame] * 4)
+    out = tracker(batch)
+    plain = det(frame)
+    assert len(out) == 4 and len(plain) > 0
+    ids0 = sorted(f['track'] for f in out[0])
+    assert ids0 == list(range(len(plain)))                       # min_hits = 0: every detection gets an id at once
+    for faces in out[1:]:
+        assert sorted(f['track'] for f in faces) == ids0         # identical detections -> identical identities
+        assert {k for f in faces for k in f} == {'track', 'bbox', 'landmarks', 'score'}
+    single = tracker(frame)                                      # single image: a list of dicts, not a list of lists
+    assert isinstance(single, list) and all('track' in f for f in single)
