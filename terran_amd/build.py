@@ -54,5 +54,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_probes(force=False):
+    """The stand-alone micro-benchmarks under tools/probe (measurement aids, not part of the library)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    pdir = os.path.join(os.path.dirname(HERE), 'tools', 'probe')
+    built = []
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not f.endswith('.hip'):
+            continue
+        src, exe = os.path.join(pdir, f), os.path.join(pdir, f[:-4])
+        if force or _stale(exe, [src]):
+            r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-Wno-unused-value', '-o', exe, src],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                raise RuntimeError('hipcc failed on %s:\n%s' % (f, r.stdout.decode(errors='replace')))
+        built.append(exe)
+    return built
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    print(build_probes(force='--force' in sys.argv))
