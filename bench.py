@@ -111,15 +111,16 @@ def main():
     sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
     frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
     F = args.faces
-    fallback_lm = synth.landmarks(77, F, H, W)
+    face_state = {'F': F}                                               # pick_faces reads the current faces-per-frame
+    fallback_lm = synth.landmarks(77, 4 if F < 4 else F, H, W)
     L = max(1, args.inflight)
     pool = ThreadPoolExecutor(max_workers=3 * L)
 
     def pick_faces(dets):
-        faces = []
+        faces, nf = [], face_state['F']
         for d in dets:
-            f = [{'landmarks': x['landmarks']} for x in d[:F]]
-            for k in range(len(f), F):                              # fewer than F detections: synthetic landmarks
+            f = [{'landmarks': x['landmarks']} for x in d[:nf]]
+            for k in range(len(f), nf):                             # fewer than F detections: synthetic landmarks
                 f.append({'landmarks': fallback_lm[k]})
             faces.append(f)
         return faces
@@ -273,6 +274,18 @@ def main():
                 others[prec] = {'value': round(args.batch * args.steps * world / e2, 3),
                                 'ms_per_step': round(e2 / args.steps * 1e3, 3), 'roofline': roofline(prec, k2)}
 
+    # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
+    other_faces = {}
+    if not args.single_mode:
+        for nf in (1, 4):
+            if nf != F:
+                face_state['F'] = nf
+                e3, _, k3 = run_mode(primary)
+                other_faces[str(nf)] = {'value': round(args.batch * args.steps * world / e3, 3),
+                                        'ms_per_step': round(e3 / args.steps * 1e3, 3),
+                                        'algorithmic_gflop_per_step': round(k3['conv_igemm']['work'] / 1e9, 1)}
+        face_state['F'] = F
+
     result = None
     if rank == 0:
         dets, feats, poses = out
@@ -316,6 +329,7 @@ def main():
             'stage_hbm_gbps': {k: round(v['work'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in klass.items()
                                if k != 'conv_igemm' and v['ms'] > 0},
             'other_precisions': others,
+            'other_faces_per_frame': other_faces,
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
