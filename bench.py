@@ -11,8 +11,10 @@ a batch of B=32 synthetic 1080p RGB frames per GPU per step, ALREADY RESIDENT in
   Estimation(short_side=184) -> OpenPose 184x327 + x8 bicubic + grouping   (pose/__init__.py)
 with random-init weights of the exact architectures (no checkpoints offline) and the full host
 side of the wrappers (result download, dict construction, landmark alignment math).
-One "step" = one such batch.  Frames shard embarrassingly: every rank owns its own batch, there
-is no data-path collective ("scaling": "weak").
+One "step" = one such batch (F = 2 faces per frame by default; F = 1 and F = 4, the counts SURVEY.md 8d quotes, are
+measured as well and reported under `other_faces_per_frame`).  Per GPU the host keeps two batches in flight, each on
+three threads / HIP streams (detect -> queue -> embed, pose); all K steps complete inside the timed region.  Frames
+shard embarrassingly: every rank owns its own batches, there is no data-path collective ("scaling": "weak").
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for `roofline` and `cpu_baseline`).
 """
