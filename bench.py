@@ -315,6 +315,9 @@ def main():
                 'faces_per_frame': F,
                 'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
                 'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
+                # the random-weight pose net rarely assembles a person but keeps the grouping stage busy:
+                'pose_peaks_per_frame': round(pipes[0].ctxs[2].pose_stats()[0] / float(args.batch), 1),
+                'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
                 'streams_per_gpu': 3 * L,
                 'batches_in_flight_per_gpu': L,

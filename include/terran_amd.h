@@ -144,6 +144,10 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
 int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w,
                       double scale, int capacity, int32_t* counts, int32_t* keypoints,
                       double* scores, int32_t* required);
+/* Workload statistics of the last ta_openpose_run / ta_openpose_group on this context: heat-map peaks found over
+ * all images and parts (wrapper.py:235-262) and limb connections accepted by the greedy matching (wrapper.py:335-366). */
+int ta_openpose_last_stats(const ta_ctx* ctx, int64_t* peaks, int64_t* connections);
+
 /* x8 bicubic upsample alone (wrapper.py:214-223): maps (N,C,h,w) -> (N,C,8h,8w). */
 int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out);
 

@@ -576,9 +576,15 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
     TA_HIP(ctx, hipGetLastError());
   }
   int ovf = 0;
+  std::vector<int> stat((size_t)N * 37);           // peaks per (image, part) and connections per (image, limb): statistics only
   TA_HIP(ctx, hipMemcpyAsync(counts, w.out_cnt, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(&ovf, w.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(stat.data(), w.peak_cnt, (size_t)N * 18 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(stat.data() + (size_t)N * 18, w.conn_cnt, (size_t)N * 19 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pose_peaks = ctx->pose_connections = 0;
+  for (size_t i = 0; i < (size_t)N * 18; ++i) ctx->pose_peaks += stat[i];
+  for (size_t i = (size_t)N * 18; i < stat.size(); ++i) ctx->pose_connections += stat[i] > 0 ? stat[i] : 0;   // -1 = limb missing
   if (ovf) return ta_fail(ctx, TA_E_OVERFLOW, "openpose: more than %d peaks per part, %d candidate pairs per limb or %d humans in one image", OP_MAXP, OP_MAXC, OP_MAXH);
   long long total = 0;
   for (int i = 0; i < N; ++i) total += counts[i];
@@ -674,6 +680,13 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(dev);
   return rc;
+}
+
+int ta_openpose_last_stats(const ta_ctx* ctx, int64_t* peaks, int64_t* connections) {
+  if (!ctx) return TA_E_INVALID;
+  if (peaks) *peaks = ctx->pose_peaks;
+  if (connections) *connections = ctx->pose_connections;
+  return TA_OK;
 }
 
 int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out) {

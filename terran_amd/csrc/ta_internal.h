@@ -92,6 +92,7 @@ struct ta_ctx {
   std::mutex frame_cache_mu;                       // frames may be released from a GC thread
   std::vector<std::pair<size_t, void*>> frame_cache;
   size_t frame_cache_bytes = 0;
+  int64_t pose_peaks = 0, pose_connections = 0;    // statistics of the last OpenPose grouping on this context
 };
 
 int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...);

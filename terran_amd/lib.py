@@ -66,6 +66,7 @@ SIGNATURES = {
     'ta_openpose_group': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p,
                                   c_void_p, c_void_p, P(C.c_int32)]),
     'ta_bicubic_x8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ta_openpose_last_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -174,6 +175,12 @@ class Context:
         out = np.empty((a.shape[0], b.shape[0]), np.float32)
         self.check(self.lib.ta_cosine_distance(self.h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1], ptr(out)))
         return out
+
+    def pose_stats(self):
+        """(peaks, limb connections) of the last OpenPose grouping run on this context."""
+        a, b = C.c_int64(), C.c_int64()
+        self.check(self.lib.ta_openpose_last_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def bicubic_x8(self, maps):
         maps = np.ascontiguousarray(maps, dtype=np.float32)
