@@ -1,23 +1,31 @@
 """ORACLE (test infrastructure only) -- CPU restatement of Terran's SORT face tracker.
 
-Follows terran/tracking/face.py: `iou` :14-44, `corners_to_center` :47-71, `center_to_corners` :74-95,
-`KalmanTracker` :98-203, `associate_detections_to_trackers` :206-272, `Sort` :275-411,
-`FaceTracking.__call__` :429-473.
+What is restated (terran/tracking/face.py): box <-> filter-state conversion :47-95, the per-face constant-velocity
+Kalman model :119-151 with its negative-area guard :196-197, IoU association through the Hungarian method with the
+0.3 gate :206-272, and the bookkeeping of `Sort.update` :333-411 (prediction, removal of non-finite tracks, id policy
+`hits >= min_hits or frame_count <= min_hits`, births, pruning by `max_age`, output order = surviving tracks in track
+order followed by births).  Tracks are plain dicts here; the arithmetic and its order are the reference's.
 
-Third-party arithmetic not under /root/reference: `filterpy.kalman.KalmanFilter` (setup.py:14, UNPINNED version,
-not importable here).  `KalmanFilter` below restates filterpy's published linear filter (defaults x = 0 (n,1),
-P = I, Q = I, R = I, F = I; predict x = F x, P = F P F' + Q; update y = z - H x, S = H P H' + R, K = P H' S^-1,
-x += K y, P = (I - K H) P (I - K H)' + K R K').  PARITY UNPINNED for that class: the golden vectors
-(tests/golden/tracking.npz) come from the reference's own Sort / KalmanTracker / association code imported in
-the build container with THIS class standing in for filterpy's.  `scipy.optimize.linear_sum_assignment` is
-importable and used as the reference uses it.
+Third-party arithmetic not under /root/reference: `filterpy.kalman.KalmanFilter` (setup.py:14, UNPINNED version, not
+importable here).  `KalmanFilter` below restates filterpy's published linear filter (defaults x = 0 (n,1), P = Q = I,
+R = I, F = I; predict x = F x, P = F P F' + Q; update y = z - H x, S = H P H' + R, K = P H' S^-1, x += K y,
+P = (I - K H) P (I - K H)' + K R K').  PARITY UNPINNED for that class: the golden vectors (tests/golden/tracking.npz)
+come from the reference's own tracker code imported in the build container with THIS class standing in for
+filterpy's.  `scipy.optimize.linear_sum_assignment` is importable and used as the reference uses it.
 """
 import numpy as np
 from scipy.optimize import linear_sum_assignment
 
+_next_id = [0]          # ids ascend over every tracker of the process (face.py:114,149-150)
+
+
+def reset_ids(start=0):
+    _next_id[0] = start
+
 
 class KalmanFilter:
-    """filterpy.kalman.KalmanFilter, the subset the tracker touches (face.py:125-151,166,185)."""
+    """filterpy.kalman.KalmanFilter, the subset the tracker touches (also the filterpy stand-in of
+    tests/golden/make_golden_tracking.py)."""
 
     def __init__(self, dim_x, dim_z):
         self.dim_x, self.dim_z = dim_x, dim_z
@@ -44,108 +52,98 @@ class KalmanFilter:
         self.P = np.dot(np.dot(I_KH, self.P), I_KH.T) + np.dot(np.dot(K, self.R), K.T)
 
 
-def iou(a, b):                                                   # face.py:14-44
-    x_min, y_min = np.maximum(a[0], b[0]), np.maximum(a[1], b[1])
-    x_max, y_max = np.minimum(a[2], b[2]), np.minimum(a[3], b[3])
-    inter = np.maximum(0.0, x_max - x_min) * np.maximum(0.0, y_max - y_min)
+def measurement(box):
+    """corner box -> column (cx, cy, area, aspect); integer boxes divide as floats."""
+    w, h = box[2] - box[0], box[3] - box[1]
+    return np.array([box[0] + w / 2.0, box[1] + h / 2.0, w * h, w / h]).reshape(4, 1)
+
+
+def state_box(x):
+    """filter state (7,1) -> flat corner box (4,)."""
+    w = np.sqrt(x[2] * x[3])
+    h = x[2] / w
+    return np.concatenate([x[0] - w / 2.0, x[1] - h / 2.0, x[0] + w / 2.0, x[1] + h / 2.0])
+
+
+def new_track(face):
+    kf = KalmanFilter(dim_x=7, dim_z=4)
+    kf.F[:3, 4:] = np.eye(3)                       # position / area integrate their velocities; aspect has none
+    kf.H[:, :4] = np.eye(4)
+    kf.R[2:, 2:] *= 10.0
+    kf.P[4:, 4:] *= 1000.0
+    kf.P *= 10.0
+    kf.Q[-1, -1] *= 0.01
+    kf.Q[4:, 4:] *= 0.01
+    kf.x[:4] = measurement(face['bbox'])
+    track = {'id': _next_id[0], 'kf': kf, 'hits': 0, 'misses': 0}
+    _next_id[0] += 1
+    return track
+
+
+def advance(track):
+    """One prediction step; returns the predicted corner box."""
+    kf = track['kf']
+    if (kf.x[6] + kf.x[2]) <= 0:
+        kf.x[6] *= 0.0
+    kf.predict()
+    track['misses'] += 1
+    return state_box(kf.x)
+
+
+def overlap(a, b):
+    iw = np.maximum(0.0, np.minimum(a[2], b[2]) - np.maximum(a[0], b[0]))
+    ih = np.maximum(0.0, np.minimum(a[3], b[3]) - np.maximum(a[1], b[1]))
+    inter = iw * ih
     return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
 
 
-def corners_to_center(bbox):                                     # face.py:47-71
-    w, h = bbox[2] - bbox[0], bbox[3] - bbox[1]
-    return np.array([bbox[0] + w / 2.0, bbox[1] + h / 2.0, w * h, w / h]).reshape((4, 1))
-
-
-def center_to_corners(s):                                        # face.py:74-95
-    w = np.sqrt(s[2] * s[3])
-    h = s[2] / w
-    return np.concatenate([s[0] - w / 2.0, s[1] - h / 2.0, s[0] + w / 2.0, s[1] + h / 2.0])
-
-
-class KalmanTracker:                                             # face.py:98-203
-    count = 0
-
-    def __init__(self, face):
-        kf = self.kf = KalmanFilter(dim_x=7, dim_z=4)
-        kf.F = np.eye(7)
-        kf.F[0, 4] = kf.F[1, 5] = kf.F[2, 6] = 1.0
-        kf.H = np.eye(4, 7)
-        kf.R[2:, 2:] *= 10.0
-        kf.P[4:, 4:] *= 1000.0
-        kf.P *= 10.0
-        kf.Q[-1, -1] *= 0.01
-        kf.Q[4:, 4:] *= 0.01
-        kf.x[:4] = corners_to_center(face['bbox'])
-        self.hits = 0
-        self.time_since_update = 0
-        self.id = KalmanTracker.count
-        KalmanTracker.count += 1
-
-    def update(self, face):
-        self.time_since_update = 0
-        self.hits += 1
-        self.kf.update(corners_to_center(face['bbox']))
-
-    def predict(self):
-        if (self.kf.x[6] + self.kf.x[2]) <= 0:
-            self.kf.x[6] *= 0.0
-        self.kf.predict()
-        self.time_since_update += 1
-        return center_to_corners(self.kf.x)
-
-
-def associate(faces, trackers, iou_threshold=0.3):               # face.py:206-272
-    if not len(trackers):
-        return np.empty((0, 2), dtype=int), np.arange(len(faces)), np.empty((0, 5), dtype=int)
-    m = np.zeros((len(faces), len(trackers)), dtype=np.float32)
-    for fi, face in enumerate(faces):
-        for ti, track in enumerate(trackers):
-            m[fi, ti] = iou(face['bbox'], track)
-    pairs = np.transpose(np.asarray(linear_sum_assignment(-m)))
-    unmatched_faces = [fi for fi in range(len(faces)) if fi not in pairs[:, 0]]
-    unmatched_trackers = [ti for ti in range(len(trackers)) if ti not in pairs[:, 1]]
-    matches = []
-    for fi, ti in pairs:
-        if m[fi, ti] < iou_threshold:
-            unmatched_faces.append(fi)
-            unmatched_trackers.append(ti)
+def assign(faces, boxes, gate=0.3):
+    """-> {track index: face index} of accepted pairs, and the face indices left over (reference order: never
+    assigned first, then gated-out pairs in assignment order)."""
+    if len(boxes) == 0:
+        return {}, list(range(len(faces)))
+    cost = np.zeros((len(faces), len(boxes)), dtype=np.float32)
+    for i, f in enumerate(faces):
+        for j, b in enumerate(boxes):
+            cost[i, j] = overlap(f['bbox'], b)
+    rows, cols = linear_sum_assignment(-cost)
+    pairs, spare = {}, [i for i in range(len(faces)) if i not in set(rows.tolist())]
+    for i, j in zip(rows.tolist(), cols.tolist()):
+        if cost[i, j] < gate:
+            spare.append(i)
         else:
-            matches.append(np.array([fi, ti], dtype=int))
-    matches = np.stack(matches) if matches else np.empty((0, 2), dtype=int)
-    return matches, np.array(unmatched_faces), np.array(unmatched_trackers)
+            pairs[j] = i
+    return pairs, spare
 
 
-class Sort:                                                      # face.py:275-411
+class Sort:
     def __init__(self, max_age=1, min_hits=3, return_unmatched=False):
         self.max_age, self.min_hits, self.return_unmatched = max_age, min_hits, return_unmatched
-        self.trackers = []
+        self.tracks = []
         self.frame_count = 0
 
     def update(self, faces):
         self.frame_count += 1
-        to_delete = []
-        tracks = np.zeros((len(self.trackers), 4))
-        for ti, track in enumerate(tracks):
-            pos = self.trackers[ti].predict()
-            track[:] = pos
-            if np.any(np.isnan(pos)):
-                to_delete.append(ti)
-        tracks = np.ma.compress_rows(np.ma.masked_invalid(tracks))
-        for t in reversed(to_delete):
-            self.trackers.pop(t)
-        matched, unmatched_faces, unmatched_tracks = associate(faces, tracks)
+        boxes = [advance(t) for t in self.tracks]
+        alive = [k for k, b in enumerate(boxes) if not np.any(np.isnan(b))]
+        self.tracks = [self.tracks[k] for k in alive]
+        boxes = [boxes[k] for k in alive]
+        pairs, spare = assign(faces, boxes)
         out = []
-        for ti, track in enumerate(self.trackers):
-            if ti not in unmatched_tracks:
-                fi = int(matched[np.where(matched[:, 1] == ti)[0], 0][0])
-                track.update(faces[fi])
-                tid = track.id if (track.hits >= self.min_hits or self.frame_count <= self.min_hits) else None
-                out.append({'track': tid, **faces[fi]})
-        for fi in unmatched_faces:
-            track = KalmanTracker(faces[fi])
-            self.trackers.append(track)
-            out.append({'track': track.id if self.min_hits == 0 else None, **faces[fi]})
+        for j, track in enumerate(self.tracks):
+            if j not in pairs:
+                continue
+            face = faces[pairs[j]]
+            track['misses'] = 0
+            track['hits'] += 1
+            track['kf'].update(measurement(face['bbox']))
+            confirmed = track['hits'] >= self.min_hits or self.frame_count <= self.min_hits
+            out.append({'track': track['id'] if confirmed else None, **face})
+        for i in spare:
+            track = new_track(faces[i])
+            self.tracks.append(track)
+            out.append({'track': track['id'] if self.min_hits == 0 else None, **faces[i]})
         if not self.return_unmatched:
             out = [f for f in out if f['track'] is not None]
-        self.trackers = [t for t in self.trackers if t.time_since_update <= self.max_age]
+        self.tracks = [t for t in self.tracks if t['misses'] <= self.max_age]
         return out

@@ -34,15 +34,15 @@ def test_oracle_matches_reference(si):
     g = golden('tracking.npz')
     pre = 's%d_' % si
     ma, mh, ru = g[pre + 'cfg'].tolist()
-    OT.KalmanTracker.count = 0
+    OT.reset_ids()
     sort = OT.Sort(max_age=ma, min_hits=mh, return_unmatched=bool(ru))
     c, f, t = _run(sort, tracking_scenario(int(g[pre + 'seed'])))
     assert np.array_equal(c, g[pre + 'out_counts'])
     assert np.array_equal(f, g[pre + 'out_face'])
     assert np.array_equal(t, g[pre + 'out_track'])
-    assert np.array_equal([tr.id for tr in sort.trackers], g[pre + 'final_ids'])
-    assert np.array_equal(np.array([tr.kf.x[:, 0] for tr in sort.trackers]).reshape(-1, 7), g[pre + 'final_x'])
-    assert np.array_equal(np.array([tr.kf.P for tr in sort.trackers]).reshape(-1, 7, 7), g[pre + 'final_P'])
+    assert np.array_equal([tr['id'] for tr in sort.tracks], g[pre + 'final_ids'])
+    assert np.array_equal(np.array([tr['kf'].x[:, 0] for tr in sort.tracks]).reshape(-1, 7), g[pre + 'final_x'])
+    assert np.array_equal(np.array([tr['kf'].P for tr in sort.tracks]).reshape(-1, 7, 7), g[pre + 'final_P'])
 
 
 @pytest.mark.parametrize('si', range(N_SCEN))
