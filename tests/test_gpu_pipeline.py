@@ -409,3 +409,13 @@ def test_face_tracking_over_device_detection(states, precision):
         assert {k for f in faces for k in f} == {'track', 'bbox', 'landmarks', 'score'}
     single = tracker(frame)                                      # single image: a list of dicts, not a list of lists
     assert isinstance(single, list) and all('track' in f for f in single)
+
+
+def test_pose_stats_follow_the_last_grouping(ctx):
+    from terran_amd import openpose
+    hm, paf = synth.pose_maps_batch(41, 2, 4, 20, 28)
+    humans = sum(len(p) for p in openpose.group(ctx, paf, hm, 1.0))
+    peaks, conns = ctx.pose_stats()
+    assert humans > 0 and peaks >= 4 * humans and conns >= 3 * humans      # a person needs >= 4 parts, >= 3 limbs
+    openpose.group(ctx, np.zeros((1, 38, 6, 8), np.float32), np.zeros((1, 19, 6, 8), np.float32), 1.0)
+    assert ctx.pose_stats() == (0, 0)
