@@ -47,8 +47,10 @@ class RawVideoReader:
     """
 
     def __init__(self, stream, width, height, batch_size=32, device=None, prefetch=DEFAULT_READER_BUFFER_SIZE,
-                 upload=None):
+                 upload=None, framerate=None):
         self.stream, self.width, self.height, self.batch_size = stream, int(width), int(height), int(batch_size)
+        self.framerate = framerate                 # frames per second of the source, as terran.io.video.Video exposes it
+                                                   # (reader.py:229-236); `face_tracking(video=reader)` derives its ages from it
         self._queue = Queue(max(1, int(prefetch)))
         self._stop = threading.Event()
         self._closed = False

@@ -93,9 +93,11 @@ def test_facetracking_wrapper_and_factory():
     with pytest.raises(ValueError):
         T.face_tracking(detector=object())
 
-    class Video:
-        framerate = 25
-    tr = T.face_tracking(video=Video(), detector=Detection(lazy=True))
+    import io
+    from terran_amd.video import RawVideoReader
+    video = RawVideoReader(io.BytesIO(b''), 8, 8, batch_size=2, upload=lambda a: a, framerate=25)   # empty stream
+    video.close()
+    tr = T.face_tracking(video=video, detector=Detection(lazy=True))
     assert (tr.tracker.max_age, tr.tracker.min_hits) == (25, 5)
     tr = T.face_tracking(detector=Detection(lazy=True), min_hits=2)
     assert (tr.tracker.max_age, tr.tracker.min_hits) == (30, 2)
