@@ -264,6 +264,11 @@ def main():
         if os.path.exists(pmc):                       # rocprofv3 --pmc passes of this same command (profiles/README.md)
             r['traffic'] = round(json.load(open(pmc))['hbm_bytes_per_launch'])
             r['traffic_source'] = 'profiles/pmc_conv_%s.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % precision
+        pm = os.path.join(REPO, 'profiles', 'pmc_mfma.json')
+        if os.path.exists(pm):                        # hardware counters on the dominant layers (profiles/README.md)
+            c = json.load(open(pm)).get(precision)
+            if c:
+                r['pmc_dominant_layers'] = dict(c, source='profiles/pmc_mfma.json (tools/clock_probe.sh)')
         return r
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'bf16x3')
