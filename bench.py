@@ -364,6 +364,7 @@ def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
     n = len(frames_host)
     t0 = time.perf_counter()
     dets = pipeline.detection(sd_r, frames_host, short_side=416)
+    t1 = time.perf_counter()
     faces = []
     for d in dets:
         f = [{'landmarks': x['landmarks']} for x in d[:F]]
@@ -371,11 +372,15 @@ def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
             f.append({'landmarks': fallback_lm[k]})
         faces.append(f)
     pipeline.recognition(sd_a, list(frames_host), faces)
+    t2 = time.perf_counter()
     pipeline.estimation(sd_p, frames_host, short_side=184, bicubic_impl='torch')
-    dt = time.perf_counter() - t0
+    t3 = time.perf_counter()
+    dt = t3 - t0
     return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '%d of the same 1080p frames through oracle.pipeline detection+recognition(top-%d)+estimation '
-                      '(torch-CPU fp32, %.1f s)' % (n, F, dt)}
+                      '(torch-CPU fp32, %.1f s)' % (n, F, dt),
+            'stage_ms_per_frame': {'detection': round((t1 - t0) / n * 1e3, 1), 'recognition': round((t2 - t1) / n * 1e3, 1),
+                                   'estimation': round((t3 - t2) / n * 1e3, 1)}}
 
 
 if __name__ == '__main__':
