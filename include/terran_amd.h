@@ -148,8 +148,38 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
  * all images and parts (wrapper.py:235-262) and limb connections accepted by the greedy matching (wrapper.py:335-366). */
 int ta_openpose_last_stats(const ta_ctx* ctx, int64_t* peaks, int64_t* connections);
 
+/* Debug taps of the last ta_openpose_run / ta_openpose_group on this context (valid until the next call on it), for
+ * parity tests of the seams between the grouping stages: per image and part the peaks found (wrapper.py:235-262, rows
+ * in the reference's row-major order), per image and limb the connections kept by the greedy matching
+ * (wrapper.py:335-366, in acceptance order).  n must equal the batch of that call.
+ *   peak_counts (n,18) int32; peaks_yx (n,18,cap_peaks,2) int32 (y,x in the x8 map); peak_scores (n,18,cap_peaks) f32
+ *   conn_counts (n,19) int32, -1 = limb skipped because one of its parts has no peak (wrapper.py:293-296);
+ *   conn_ij (n,19,cap_conn,2) int32 (index into the source / destination part's peak list); conn_scores (n,19,cap_conn) f32
+ * Rows beyond cap_* are dropped (the counts still report the true numbers). */
+int ta_openpose_debug_read(ta_ctx* ctx, int n, int cap_peaks, int32_t* peak_counts, int32_t* peaks_yx,
+                           float* peak_scores, int cap_conn, int32_t* conn_counts, int32_t* conn_ij,
+                           float* conn_scores);
+
 /* x8 bicubic upsample alone (wrapper.py:214-223): maps (N,C,h,w) -> (N,C,8h,8w). */
 int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, float* out);
+
+/* ---- conv kernel selection (parity tests and tools) ------------------------------------------ */
+/* Every dense conv / FC of the three networks runs on one of these implicit-GEMM kernels (terran_amd/csrc/conv_igemm.hip);
+ * the library picks per layer (TA_CONV_AUTO).  ta_debug_conv_variant makes every following conv launch on this context
+ * that the variant CAN run use it (layers it cannot run stay automatic); a packed model may also pin single convs to a
+ * variant (ta_op_desc.variant, terran_amd/pack.py `variant=`), which fails with TA_E_INVALID when that kernel cannot run
+ * the layer.  ta_debug_conv_counts reports (and optionally clears) the launches per variant since the last reset,
+ * counts16[TA_CONV_*], so a parity test knows which kernels produced the numbers it compared. */
+#define TA_CONV_AUTO 0
+#define TA_CONV_GENERIC 1      /* K-offset table, any Cin, float32 activations                       */
+#define TA_CONV_PIPE64 2       /* 64 cout x 128 px tiles, symmetric waves, 3-stage LDS ring          */
+#define TA_CONV_PIPE128 3      /* 128 x 128 tiles, symmetric waves (float32 activations only)        */
+#define TA_CONV_SPLIT_2x2 4    /* producer/consumer waves, 128 cout x 128 px                         */
+#define TA_CONV_SPLIT_2x2_P8 5 /* ... with 8 producer waves                                          */
+#define TA_CONV_SPLIT_2x4 6    /* producer/consumer waves, 128 cout x 256 px (8 consumer waves)      */
+#define TA_CONV_SPLIT_1x4 7    /* producer/consumer waves, 64 cout x 256 px                          */
+int ta_debug_conv_variant(ta_ctx* ctx, int variant);
+int ta_debug_conv_counts(ta_ctx* ctx, int64_t* counts16, int reset);
 
 #ifdef __cplusplus
 }

@@ -938,14 +938,17 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     int stage = 2;                                  // stage the next issued slab goes to
     for (int s = 0; s < S; ++s) {
       // slab s must have landed; issue order was [A0 A1 B0 B1] then [A B] per slab, and vmcnt counts in issue order
-      if (s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - QA) : "memory");
+      if (p.probe && s > 0) {                        // tools only (timing ablation): fewer DMAs in flight
+        if (p.probe == 1 && s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - QA) : "memory");
       else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // B_s: slab s landed (all producers); consumers have drained slab s-1
       asm volatile("" ::: "memory");
       if (s + 2 < S) {
-        issue_a(s + 2, stage);
-        issue_b(stage);
+        if (p.probe != 2) issue_a(s + 2, stage);
+        if (!p.probe) issue_b(stage);
         stage = stage == 2 ? 0 : stage + 1;
       }
     }
@@ -1118,11 +1121,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm_split<CM, CN, NP, PREC, STAGES>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   if (p.k_split > 1) {
@@ -1142,12 +1141,7 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
-    attr_set = true;
-  }
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
@@ -1162,71 +1156,116 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm_pipe<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES, BSPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TA_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }
 
-template <int PREC>
-static int launch_prec(ta_ctx* ctx, const ta_conv_launch& p) {
-  // TA_CONV_CFG: kernel A/B experiments only (9 = table-driven 2-stage kernel everywhere, 2 = 128x128 pipe tiles,
-  // 1 = symmetric 64x128 pipe kernel instead of the split-role kernel, 31 = split-role kernel with 8 producer waves,
-  // 40 = 128x256 tiles wherever possible, 42 = never)
-  static const int cfg = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
-  if (p.uniform_k && p.n_slabs >= 2 && cfg != 9) {
-    if constexpr (PREC != PREC_F32) {
-      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 128 == 0 && cfg != 1) {
-        if (cfg == 31) return launch_split<2, 2, 8, PREC, 3>(ctx, p);
-        if (cfg == 40) return launch_split<2, 4, 4, PREC, 3>(ctx, p);
-        if (cfg != 42 && p.k_split == 1) {
-          // 128 x 256 tiles (8 consumer waves) stream 25 % fewer DMA bytes per FLOP and measure ~8 % faster per tile
-          // pair, but a CU holds one workgroup either way: take them when they do not cost a round of the 256 CUs
-          const int n_ct = p.coutp / 128;
-          const int t1 = ((p.M + 127) / 128) * n_ct, t2 = ((p.M + 255) / 256) * n_ct;
-          const int r1 = (t1 + 255) / 256, r2 = (t2 + 255) / 256;
-          if (r2 * 184 < r1 * 100) return launch_split<2, 4, 4, PREC, 3>(ctx, p);
-        }
-        return launch_split<2, 2, 4, PREC, 3>(ctx, p);
-      }
-      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, 4, PREC, 3>(ctx, p);
-      if (p.in_fmt == TA_FMT_SPLIT && p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
-    }
-    if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
-    if constexpr (PREC == PREC_F32) {
-      if (p.coutp % 128 == 0 && cfg != 1) return launch_split<2, 2, 4, PREC, 3>(ctx, p);
-      if (p.coutp % 64 == 0 && cfg != 1 && cfg != 4) return launch_split<1, 4, 4, PREC, 3>(ctx, p);
-    }
-    if (cfg == 2 && p.coutp % 128 == 0) return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
-    if (p.coutp % 64 == 0) return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
+// ---- kernel selection ---------------------------------------------------------------------------------------------
+// Which variants can run this conv at all (a forced variant that cannot is an error, never a silent substitution).
+static bool variant_eligible(int v, const ta_conv_launch& p) {
+  const bool split_in = p.prec == PREC_F32 ? p.in_fmt == TA_FMT_F32 : p.in_fmt == TA_FMT_SPLIT;   // what the split-role kernel reads
+  const bool deep = p.uniform_k && p.n_slabs >= 2;
+  switch (v) {
+    case TA_CV_GENERIC: return p.in_fmt == TA_FMT_F32 && !p.group_cout;
+    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || p.prec != PREC_F32);
+    case TA_CV_PIPE128: return deep && p.coutp % 128 == 0 && !p.group_cout && p.in_fmt == TA_FMT_F32;
+    case TA_CV_SPLIT_2x2:
+    case TA_CV_SPLIT_2x2_P8:
+    case TA_CV_SPLIT_2x4: return deep && split_in && p.coutp % 128 == 0;
+    case TA_CV_SPLIT_1x4: return deep && split_in && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0);
   }
-  if (p.in_fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
-  if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2, PREC>(ctx, p);
-  if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
-  return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
+  return false;
+}
+
+// The automatic choice.
+static int choose_variant(const ta_conv_launch& p) {
+  if (p.uniform_k && p.n_slabs >= 2) {
+    if (variant_eligible(TA_CV_SPLIT_2x2, p)) {
+      if (p.prec != PREC_F32 && p.k_split == 1) {
+        // 128 x 256 tiles (8 consumer waves) stream 25 % fewer DMA bytes per FLOP and measure ~8 % faster per tile
+        // pair, but a CU holds one workgroup either way: take them when they do not cost a round of the 256 CUs
+        const int n_ct = p.coutp / 128;
+        const int t1 = ((p.M + 127) / 128) * n_ct, t2 = ((p.M + 255) / 256) * n_ct;
+        const int r1 = (t1 + 255) / 256, r2 = (t2 + 255) / 256;
+        if (r2 * 184 < r1 * 100) return TA_CV_SPLIT_2x4;
+      }
+      return TA_CV_SPLIT_2x2;
+    }
+    if (variant_eligible(TA_CV_SPLIT_1x4, p)) return TA_CV_SPLIT_1x4;
+    if (variant_eligible(TA_CV_PIPE64, p)) return TA_CV_PIPE64;
+  }
+  return TA_CV_GENERIC;
+}
+
+template <int PREC>
+static int launch_variant(ta_ctx* ctx, int v, const ta_conv_launch& p) {
+  switch (v) {
+    case TA_CV_GENERIC:
+      if (p.coutp % 128 == 0) return launch_cfg<2, 2, 2, 2, PREC>(ctx, p);
+      if (p.coutp % 64 == 0) return launch_cfg<1, 4, 2, 1, PREC>(ctx, p);
+      return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
+    case TA_CV_PIPE64:
+      if constexpr (PREC != PREC_F32) {
+        if (p.in_fmt == TA_FMT_SPLIT) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
+      }
+      return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
+    case TA_CV_PIPE128: return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
+    case TA_CV_SPLIT_2x2: return launch_split<2, 2, 4, PREC, 3>(ctx, p);
+    case TA_CV_SPLIT_2x2_P8: return launch_split<2, 2, 8, PREC, 3>(ctx, p);
+    case TA_CV_SPLIT_2x4: return launch_split<2, 4, 4, PREC, 3>(ctx, p);
+    case TA_CV_SPLIT_1x4: return launch_split<1, 4, 4, PREC, 3>(ctx, p);
+  }
+  return ta_fail(ctx, TA_E_INVALID, "conv: unknown kernel variant %d", v);
 }
 
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p_in.M <= 0) return TA_OK;
   static const int direct = getenv("TA_CONV_DIRECT_EPILOGUE") ? 1 : 0;      // A/B switch: accumulators straight to global
+  static const int no_ksplit = getenv("TA_CONV_NO_KSPLIT") ? 1 : 0;         // A/B switch
   ta_conv_launch p = p_in;
   p.direct_epilogue = direct;
-  if (p.k_split < 1 || !p.partial) p.k_split = 1;
-  static const int no_ksplit = getenv("TA_CONV_NO_KSPLIT") ? 1 : 0;            // A/B switch
-  static const int cfg_env = getenv("TA_CONV_CFG") ? atoi(getenv("TA_CONV_CFG")) : 0;
-  if (no_ksplit || cfg_env == 1 || cfg_env == 2 || cfg_env == 9) p.k_split = 1;    // only the split-role kernel knows K ranges
-  if (p.group_cout && (cfg_env == 1 || cfg_env == 2 || cfg_env == 9))
-    return ta_fail(ctx, TA_E_INVALID, "conv: grouped convolutions need the split-role kernel (TA_CONV_CFG=%d)", cfg_env);
+  p.probe = ctx->conv_probe;
+  if (p.k_split < 1 || !p.partial || no_ksplit) p.k_split = 1;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
+  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16)
+    return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
+  int v = p.variant;
+  if (v != TA_CV_AUTO) {
+    if (!variant_eligible(v, p))
+      return ta_fail(ctx, TA_E_INVALID, "conv: forced kernel variant %d cannot run this layer (cin-uniform %d, slabs %d, coutp %d, "
+                     "input format %d, groups %d)", v, p.uniform_k, p.n_slabs, p.coutp, p.in_fmt, p.group_cout ? 1 : 0);
+  } else {
+    v = ctx->conv_force && variant_eligible(ctx->conv_force, p) ? ctx->conv_force : choose_variant(p);
+    if (!variant_eligible(v, p)) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
+  }
+  const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4;
+  if (!is_split) p.k_split = 1;                                              // only the split-role kernel knows K ranges
+  ctx->conv_counts[v] += 1;
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {
-    case PREC_F32: return launch_prec<PREC_F32>(ctx, p);
-    case PREC_BF16X3: return launch_prec<PREC_BF16X3>(ctx, p);
-    case PREC_BF16: return launch_prec<PREC_BF16>(ctx, p);
+    case PREC_F32: return launch_variant<PREC_F32>(ctx, v, p);
+    case PREC_BF16X3: return launch_variant<PREC_BF16X3>(ctx, v, p);
+    default: return launch_variant<PREC_BF16>(ctx, v, p);
   }
-  return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
 }
+
+extern "C" {
+
+int ta_debug_conv_variant(ta_ctx* ctx, int variant) {
+  if (!ctx || variant < 0 || variant >= TA_CV_COUNT) return TA_E_INVALID;
+  ctx->conv_force = variant;
+  return TA_OK;
+}
+
+int ta_debug_conv_counts(ta_ctx* ctx, int64_t* counts16, int reset) {
+  if (!ctx) return TA_E_INVALID;
+  for (int i = 0; i < TA_CV_COUNT; ++i) {
+    if (counts16) counts16[i] = ctx->conv_counts[i];
+    if (reset) ctx->conv_counts[i] = 0;
+  }
+  return TA_OK;
+}
+
+}  // extern "C"

@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* in, float* o
   }
 }
 
-int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out) {
-  const size_t total = (size_t)out.n * out.h * out.w * (out.c / 4);
+int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out, int n) {
+  const size_t total = (size_t)n * out.h * out.w * (out.c / 4);
   if (!total) return TA_OK;
   ta_prof_scope scope(ctx, 1, (double)total * 16 * 5);
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, in.fmt, out.fmt, out.n, out.h,
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, in.fmt, out.fmt, n, out.h,
                      out.w, out.c, (int)((size_t)in.hp() * in.wp() * in.c), in.wp() * in.c, in.c,
                      (int)in.off(0, 0, 0), (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c, out.c,
                      (int)out.off(0, 0, 0));
@@ -110,14 +110,14 @@ __global__ __launch_bounds__(256) void copych_kernel(const float* in, float* out
   }
 }
 
-int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch) {
+int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch, int n) {
   // raw 16-byte copies: with pre-split tensors the slice must be whole 32-channel blocks in the same format
   if (in.fmt != out.fmt || (in.fmt == TA_FMT_SPLIT && ((in_ch | out_ch | ch) & 31)))
     return ta_fail(ctx, TA_E_INVALID, "copych: incompatible tensor formats");
-  const size_t total = (size_t)in.n * in.h * in.w * (ch / 4);
+  const size_t total = (size_t)n * in.h * in.w * (ch / 4);
   if (!total) return TA_OK;
   ta_prof_scope scope(ctx, 1, (double)total * 16 * 2);
-  hipLaunchKernelGGL(copych_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, in.n, in.h, in.w,
+  hipLaunchKernelGGL(copych_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.dev, out.dev, n, in.h, in.w,
                      ch, (int)((size_t)in.hp() * in.wp() * in.c), in.wp() * in.c, in.c, (int)in.off(0, 0, 0) + in_ch,
                      (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c, out.c,
                      (int)out.off(0, 0, 0) + out_ch);

@@ -54,9 +54,23 @@ static void free_plans(ta_model* m) {
   m->ktab_dev = nullptr;
 }
 
-int ta_model_plan(ta_model* m, int n, int h, int w) {
+// Batch capacity a plan is carved for.  Frame batches (RetinaFace / OpenPose) come in a few fixed sizes; the ArcFace
+// batch is the number of faces in a frame batch and changes on almost every call of a video loop, so its plans are
+// carved for a bucketed capacity (8, 32, then multiples of 64) and reused for every smaller count: no stream sync,
+// hipMalloc / memset of a multi-GB arena or eviction hipFree per distinct face count.  Launches always cover exactly
+// the n crops of the call (ta_model::run_n); the unused tail of the arena is never touched.
+static int plan_capacity(int kind, int n) {
+  if (kind != TA_MODEL_ARCFACE) return n;
+  if (n <= 8) return 8;
+  if (n <= 32) return 32;
+  return (n + 63) / 64 * 64;
+}
+
+int ta_model_plan(ta_model* m, int n_run, int h, int w) {
   ta_ctx* ctx = m->ctx;
-  if (n <= 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "plan: bad input shape %dx%dx%d", n, h, w);
+  if (n_run <= 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "plan: bad input shape %dx%dx%d", n_run, h, w);
+  const int n = plan_capacity(m->kind, n_run);
+  m->run_n = n_run;
   if (m->active && m->plan_n == n && m->plan_h == h && m->plan_w == w) {
     m->active->last_use = ++m->use_counter;
     return TA_OK;
@@ -245,7 +259,7 @@ int ta_model_run_ops(ta_model* m) {
         p.bias = wptr(m, op.bias_off);
         p.prelu = wptr(m, op.prelu_off);
         p.out = to.dev;
-        p.M = to.n * to.h * to.w;
+        p.M = m->run_n * to.h * to.w;
         p.Ho = to.h;
         p.Wo = to.w;
         p.n_slabs = op.n_slabs;
@@ -297,6 +311,7 @@ int ta_model_run_ops(ta_model* m) {
           p.group_cout = op.cout / op.groups;
           p.group_cin = op.cin;
         }
+        p.variant = op.variant;
         p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt)) : 1;
         p.partial = m->splitk_ws;
         TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
@@ -309,7 +324,7 @@ int ta_model_run_ops(ta_model* m) {
         p.w = wptr(m, op.w_off);
         p.bias = wptr(m, op.bias_off);
         p.out = to.dev;
-        p.N = to.n;
+        p.N = m->run_n;
         p.Ho = to.h;
         p.Wo = to.w;
         p.C = op.cin;
@@ -330,10 +345,10 @@ int ta_model_run_ops(ta_model* m) {
         break;
       }
       case TA_OP_MAXPOOL:
-        TA_TRY(ta_launch_maxpool(ctx, ti, to));
+        TA_TRY(ta_launch_maxpool(ctx, ti, to, m->run_n));
         break;
       case TA_OP_COPYCH:
-        TA_TRY(ta_launch_copych(ctx, ti, op.in_ch_off, to, op.out_ch_off, op.cin));
+        TA_TRY(ta_launch_copych(ctx, ti, op.in_ch_off, to, op.out_ch_off, op.cin, m->run_n));
         break;
     }
   }
@@ -444,7 +459,7 @@ int ta_model_forward_crops(ta_model* m, const uint8_t* crops, int n) {
 int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* w) {
   if (!m || tensor < 0 || tensor >= (int)m->tensors.size()) return TA_E_INVALID;
   const ta_tensor& t = m->tensors[tensor];
-  if (n) *n = t.n;
+  if (n) *n = m->run_n;
   if (c) *c = t.c;
   if (h) *h = t.h;
   if (w) *w = t.w;
@@ -457,10 +472,10 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
   ta_ctx* ctx = m->ctx;
   const ta_tensor& t = m->tensors[tensor];
   if (!t.dev || ch_off < 0 || ch <= 0 || ch_off + ch > t.c) return ta_fail(ctx, TA_E_INVALID, "read_tensor: bad slice");
-  std::vector<float> host(t.elems());
+  std::vector<float> host((size_t)m->run_n * t.hp() * t.wp() * t.c);
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TA_HIP(ctx, hipMemcpy(host.data(), t.dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
-  for (int i = 0; i < t.n; ++i)
+  for (int i = 0; i < m->run_n; ++i)
     for (int c = 0; c < ch; ++c)
       for (int y = 0; y < t.h; ++y)
         for (int x = 0; x < t.w; ++x)

@@ -518,12 +518,7 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
     const int strips = (m.w + BC_TW - 1) / BC_TW;
     const int lw = (m.w < BC_TW ? m.w : BC_TW) + 4;
     const size_t lds = (size_t)5 * 57 * (lw | 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      TA_HIP(ctx, hipFuncSetAttribute((const void*)bicubic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((size_t)5 * 57 * ((BC_TW + 4) | 1) * sizeof(float))));
-      attr_set = true;
-    }
+    TA_SET_LDS_ATTR(ctx, bicubic_kernel, (size_t)5 * 57 * ((BC_TW + 4) | 1) * sizeof(float));
     // the x weights depend only on the phase x % 8: entries 8..15 of the table are an interior period
     hipLaunchKernelGGL(bicubic_kernel, dim3(m.h, strips, N), dim3(256), lds, ctx->stream, m, N, up, ywt,
                        xwt + (m.w >= 2 ? 32 : 0));
@@ -554,6 +549,14 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   w.out_kp = (int*)(scr + o_okp);
   w.out_sc = (double*)(scr + o_osc);
   TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, 4, ctx->stream));
+  ctx->pose_dbg.n = N;
+  ctx->pose_dbg.maxp = OP_MAXP;
+  ctx->pose_dbg.peak_cnt = w.peak_cnt;
+  ctx->pose_dbg.peak_yx = w.peak_yx;
+  ctx->pose_dbg.peak_sc = w.peak_sc;
+  ctx->pose_dbg.conn_cnt = w.conn_cnt;
+  ctx->pose_dbg.conn_ij = w.conn_ij;
+  ctx->pose_dbg.conn_sc = w.conn_sc;
   {
     ta_prof_scope scope(ctx, 3, (double)N * 18 * H8 * W8 * 4);
     hipLaunchKernelGGL(peaks_kernel, dim3(N * 18), dim3(1024), 0, ctx->stream, w);
@@ -562,11 +565,7 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   {
     ta_prof_scope scope(ctx, 3, 0.0);
     const size_t lds = (size_t)OP_MAXC * 8 + OP_MAXP / 8 + 64;
-    static bool attr = false;
-    if (!attr) {
-      TA_HIP(ctx, hipFuncSetAttribute((const void*)limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    TA_SET_LDS_ATTR(ctx, limbs_kernel, lds);
     hipLaunchKernelGGL(limbs_kernel, dim3(N * 19), dim3(256), lds, ctx->stream, w);
     TA_HIP(ctx, hipGetLastError());
   }
@@ -686,6 +685,34 @@ int ta_openpose_last_stats(const ta_ctx* ctx, int64_t* peaks, int64_t* connectio
   if (!ctx) return TA_E_INVALID;
   if (peaks) *peaks = ctx->pose_peaks;
   if (connections) *connections = ctx->pose_connections;
+  return TA_OK;
+}
+
+int ta_openpose_debug_read(ta_ctx* ctx, int n, int cap_peaks, int32_t* peak_counts, int32_t* peaks_yx, float* peak_scores,
+                           int cap_conn, int32_t* conn_counts, int32_t* conn_ij, float* conn_scores) {
+  ta_enter(ctx);
+  if (!ctx || n <= 0 || cap_peaks < 0 || cap_conn < 0) return TA_E_INVALID;
+  const auto& d = ctx->pose_dbg;
+  if (d.n != n || !d.peak_cnt) return ta_fail(ctx, TA_E_INVALID, "openpose_debug_read: the last grouping on this context had %d images, not %d", d.n, n);
+  const int P = d.maxp;
+  std::vector<int> pc((size_t)n * 18), cc((size_t)n * 19);
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TA_HIP(ctx, hipMemcpy(pc.data(), d.peak_cnt, pc.size() * 4, hipMemcpyDeviceToHost));
+  TA_HIP(ctx, hipMemcpy(cc.data(), d.conn_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
+  if (peak_counts) memcpy(peak_counts, pc.data(), pc.size() * 4);
+  if (conn_counts) memcpy(conn_counts, cc.data(), cc.size() * 4);
+  for (int i = 0; i < n * 18; ++i) {
+    const int k = pc[i] < cap_peaks ? pc[i] : cap_peaks;
+    if (k <= 0) continue;
+    if (peaks_yx) TA_HIP(ctx, hipMemcpy(peaks_yx + (size_t)i * cap_peaks * 2, d.peak_yx + (size_t)i * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
+    if (peak_scores) TA_HIP(ctx, hipMemcpy(peak_scores + (size_t)i * cap_peaks, d.peak_sc + (size_t)i * P, (size_t)k * 4, hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < n * 19; ++i) {
+    const int k = cc[i] < cap_conn ? cc[i] : cap_conn;
+    if (k <= 0) continue;
+    if (conn_ij) TA_HIP(ctx, hipMemcpy(conn_ij + (size_t)i * cap_conn * 2, d.conn_ij + (size_t)i * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
+    if (conn_scores) TA_HIP(ctx, hipMemcpy(conn_scores + (size_t)i * cap_conn, d.conn_sc + (size_t)i * P, (size_t)k * 4, hipMemcpyDeviceToHost));
+  }
   return TA_OK;
 }
 

@@ -14,6 +14,7 @@
 
 #define RF_THREADS 1024
 #define RF_LDS_KEYS 8192
+#define RF_LDS_MAX (159 * 1024)     // dynamic LDS the kernel may be launched with (the attribute and the limit check agree)
 
 struct rf_level {
   const float* head;   // NHWC, 32 channels: cls[0:4] | bbox[4:12] | landmark[12:32]
@@ -284,14 +285,10 @@ static int rf_postprocess_dev(ta_ctx* ctx, const ta_tensor heads[3], int N, int 
   p.counts = (int*)(scr + o_counts);
   p.ncand = (int*)(scr + o_ncand);
   const size_t lds = (size_t)RF_LDS_KEYS * 8 + (size_t)(((T + 31) / 32 + 3) / 4 * 4) * 4 + 32 * 4;
-  if (lds > 160 * 1024 - 1024) return ta_fail(ctx, TA_E_OVERFLOW, "retinaface: %d anchors per image exceed the NMS bitmap limit", T);
+  if (lds > RF_LDS_MAX) return ta_fail(ctx, TA_E_OVERFLOW, "retinaface: %d anchors per image exceed the NMS bitmap limit", T);
   {
     ta_prof_scope scope(ctx, 3, (double)N * T * 32 * 4);
-    static bool attr = false;
-    if (!attr) {
-      TA_HIP(ctx, hipFuncSetAttribute((const void*)rf_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr = true;
-    }
+    TA_SET_LDS_ATTR(ctx, rf_select_kernel, RF_LDS_MAX);
     hipLaunchKernelGGL(rf_select_kernel, dim3(N), dim3(RF_THREADS), lds, ctx->stream, p);
     TA_HIP(ctx, hipGetLastError());
   }

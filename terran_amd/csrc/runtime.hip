@@ -1,6 +1,7 @@
 // Context, error text, scratch, HIP-event profiling, and device-resident uint8 frame batches
 // (upload, cv2-style bilinear resize, zero-pad paste).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ta_internal.h"
@@ -110,6 +111,9 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   }
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
+  // measurement aids for tools/ (the shipped path leaves both unset)
+  if (const char* e = getenv("TA_CONV_PREFER")) ctx->conv_force = atoi(e);
+  if (const char* e = getenv("TA_CONV_PROBE")) ctx->conv_probe = atoi(e);
   *out = ctx;
   return TA_OK;
 }
@@ -349,6 +353,8 @@ static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames**
 }
 
 int ta_frames_upload(ta_ctx* ctx, const uint8_t* nhwc_rgb, int n, int h, int w, ta_frames** out) {
+  if (!ctx || !out) return TA_E_INVALID;
+  ta_enter(ctx);            // hipMalloc below must land on the context's GPU, whatever the calling thread used last
   if (!nhwc_rgb && n > 0) return ta_fail(ctx, TA_E_INVALID, "frames_upload: null data");
   TA_TRY(frames_alloc(ctx, n, h, w, false, out));
   const size_t bytes = (size_t)n * h * w * 3;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -51,7 +52,7 @@ struct ta_op_desc {
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
   int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (f32-class), 2 = bf16 (throughput)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
-  int32_t reserved;
+  int32_t variant;                    // 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests)
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
@@ -93,7 +94,43 @@ struct ta_ctx {
   std::vector<std::pair<size_t, void*>> frame_cache;
   size_t frame_cache_bytes = 0;
   int64_t pose_peaks = 0, pose_connections = 0;    // statistics of the last OpenPose grouping on this context
+  // where the last grouping left its per-stage results in the scratch block (ta_openpose_debug_read); n = 0: none
+  struct {
+    int n = 0, maxp = 0;
+    const int *peak_cnt = nullptr, *peak_yx = nullptr, *conn_cnt = nullptr, *conn_ij = nullptr;
+    const float *peak_sc = nullptr, *conn_sc = nullptr;
+  } pose_dbg;
+  // conv kernel selection (ta_debug_conv_variant, or TA_CONV_PREFER for tools): 0 = automatic, else the TA_CV_* variant
+  // every conv that variant CAN run is launched on (others stay automatic);
+  // conv_counts[v] = launches per variant since the last ta_debug_conv_counts(reset)
+  int conv_force = 0;
+  int conv_probe = 0;                              // tools only (TA_CONV_PROBE): timing ablations of the split kernel
+  int64_t conv_counts[16] = {0};
 };
+
+// Conv kernel variants (ta_debug_conv_variant / ta_debug_conv_counts; include/terran_amd.h lists them)
+enum {
+  TA_CV_AUTO = 0,
+  TA_CV_GENERIC = 1,      // conv_igemm<...>: K-offset table, any Cin, float32 activations, 2 LDS stages
+  TA_CV_PIPE64 = 2,       // conv_igemm_pipe<1,4,2,1>: 64 cout x 128 px, every wave issues DMA + MFMA
+  TA_CV_PIPE128 = 3,      // conv_igemm_pipe<2,2,2,2>: 128 x 128 (float32 activations only)
+  TA_CV_SPLIT_2x2 = 4,    // conv_igemm_split<2,2,4>: 128 cout x 128 px, 4 consumer + 4 producer waves
+  TA_CV_SPLIT_2x2_P8 = 5, // conv_igemm_split<2,2,8>: same tile, 8 producer waves
+  TA_CV_SPLIT_2x4 = 6,    // conv_igemm_split<2,4,4>: 128 x 256, 8 consumer waves
+  TA_CV_SPLIT_1x4 = 7,    // conv_igemm_split<1,4,4>: 64 cout x 256 px
+  TA_CV_COUNT = 16
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: set it once per (kernel, device), not once per process
+#define TA_SET_LDS_ATTR(ctx, kern, bytes)                                                                         \
+  do {                                                                                                            \
+    static std::atomic<unsigned long long> _done{0};                                                              \
+    const unsigned long long _bit = 1ull << ((ctx)->device & 63);                                                 \
+    if (!(_done.load(std::memory_order_acquire) & _bit)) {                                                        \
+      TA_HIP(ctx, hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      _done.fetch_or(_bit, std::memory_order_release);                                                            \
+    }                                                                                                             \
+  } while (0)
 
 int ta_fail(ta_ctx* ctx, int code, const char* fmt, ...);
 // HIP's current device is per host thread: every ABI entry point binds the calling thread to the ctx's GPU.
@@ -171,6 +208,9 @@ struct ta_conv_launch {
   int group_cout, group_cin;                   // grouped conv: output channels / input channels per group (0 = dense)
   int k_split;                                 // > 1: K is cut in k_split ranges, one workgroup each; raw sums go to
   float* partial;                              //      partial[k][pixel][coutp] and splitk_reduce_kernel finishes the op
+  int variant;                                 // TA_CV_* this launch must use (0 = choose); an ineligible one is an error
+  int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
+                                               //             2 = no DMA at all after the ring is full (WRONG results)
 };
 
 // K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
@@ -195,8 +235,8 @@ struct ta_dw_launch {
   int out_img, out_row, out_pix, out_off0, out_fmt;
 };
 int ta_launch_dwconv(ta_ctx* ctx, const ta_dw_launch& p);
-int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out);
-int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch);
+int ta_launch_maxpool(ta_ctx* ctx, const ta_tensor& in, const ta_tensor& out, int n);   // n images (<= tensor capacity)
+int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch, int n);
 
 // pre-processing: uint8 frames -> float NHWC(4) with halo
 enum { TA_PRE_RETINAFACE = 1, TA_PRE_OPENPOSE = 2, TA_PRE_ARCFACE_CROPS = 3 };
@@ -229,7 +269,8 @@ struct ta_model {
   std::vector<ta_plan*> plans;
   ta_plan* active = nullptr;
   uint64_t use_counter = 0;
-  int plan_n = 0, plan_h = 0, plan_w = 0;
+  int plan_n = 0, plan_h = 0, plan_w = 0;      // plan_n = CAPACITY of the active plan (>= run_n)
+  int run_n = 0;                                // images / crops of the current call: every launch covers run_n, not plan_n
   std::vector<ta_tensor> tensors;
   int32_t* ktab_dev = nullptr;
   std::vector<size_t> ktab_off;

@@ -67,7 +67,15 @@ SIGNATURES = {
                                   c_void_p, c_void_p, P(C.c_int32)]),
     'ta_bicubic_x8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ta_openpose_last_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ta_openpose_debug_read': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p]),
+    'ta_debug_conv_variant': (c_int, [c_void_p, c_int]),
+    'ta_debug_conv_counts': (c_int, [c_void_p, c_void_p, c_int]),
 }
+
+# conv kernel variants (include/terran_amd.h TA_CONV_*)
+CONV_VARIANTS = {'auto': 0, 'generic': 1, 'pipe64': 2, 'pipe128': 3, 'split_2x2': 4, 'split_2x2_p8': 5, 'split_2x4': 6,
+                 'split_1x4': 7}
 
 _lib = None
 
@@ -175,6 +183,34 @@ class Context:
         out = np.empty((a.shape[0], b.shape[0]), np.float32)
         self.check(self.lib.ta_cosine_distance(self.h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1], ptr(out)))
         return out
+
+    def conv_variant(self, name):
+        """Debug: force every following conv on this context onto one kernel variant ('auto' to release)."""
+        self.check(self.lib.ta_debug_conv_variant(self.h, CONV_VARIANTS[name]))
+
+    def conv_counts(self, reset=False):
+        """Debug: {variant name: conv launches since the last reset}."""
+        c = np.zeros(16, np.int64)
+        self.check(self.lib.ta_debug_conv_counts(self.h, ptr(c), int(reset)))
+        return {k: int(c[v]) for k, v in CONV_VARIANTS.items() if v and c[v]}
+
+    def pose_debug(self, n, cap_peaks=1024, cap_conn=1024):
+        """Debug taps of the last OpenPose run / grouping on this context -> (peaks, connections):
+        peaks[i][part] = (yx (k,2) int32, scores (k,) f32); connections[i][limb] = None (limb skipped) or
+        (ij (k,2) int32, scores (k,) f32)."""
+        pc = np.zeros((n, 18), np.int32)
+        pyx = np.zeros((n, 18, cap_peaks, 2), np.int32)
+        psc = np.zeros((n, 18, cap_peaks), np.float32)
+        cc = np.zeros((n, 19), np.int32)
+        cij = np.zeros((n, 19, cap_conn, 2), np.int32)
+        csc = np.zeros((n, 19, cap_conn), np.float32)
+        self.check(self.lib.ta_openpose_debug_read(self.h, n, cap_peaks, ptr(pc), ptr(pyx), ptr(psc), cap_conn,
+                                                   ptr(cc), ptr(cij), ptr(csc)))
+        assert pc.max(initial=0) <= cap_peaks and cc.max(initial=0) <= cap_conn
+        peaks = [[(pyx[i, p, :pc[i, p]].copy(), psc[i, p, :pc[i, p]].copy()) for p in range(18)] for i in range(n)]
+        conns = [[None if cc[i, l] < 0 else (cij[i, l, :cc[i, l]].copy(), csc[i, l, :cc[i, l]].copy())
+                  for l in range(19)] for i in range(n)]
+        return peaks, conns
 
     def pose_stats(self):
         """(peaks, limb connections) of the last OpenPose grouping run on this context."""

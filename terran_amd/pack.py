@@ -33,7 +33,7 @@ HEADER_DT = np.dtype({
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
 FMT_F32, FMT_SPLIT = 0, 1
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
-           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'reserved']
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 136 and TENSOR_DT.itemsize == 16
@@ -109,12 +109,14 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None, groups=1):
+             scale2=None, shift2=None, groups=1, variant=0):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
         ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
         groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
         [in_ch_off + g cin_g, + cin_g) and writes output channels [out_ch_off + g cout_g, + cout_g); cin_g a multiple
-        of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups)."""
+        of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups).
+        variant != 0 pins the conv to one kernel variant (lib.CONV_VARIANTS; parity tests): loading fails when that
+        kernel cannot run the layer."""
         W = np.asarray(W, dtype=np.float64)
         cout, cin, kh, kw = W.shape
         if groups > 1:
@@ -147,7 +149,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
-                  groups=groups, reserved=0, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, variant=variant, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -158,7 +160,7 @@ class Program:
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
-                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
@@ -166,7 +168,7 @@ class Program:
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
-                  prec=0, groups=1, reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  prec=0, groups=1, variant=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
                   macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)

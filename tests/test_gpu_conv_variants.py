@@ -1,0 +1,208 @@
+"""-m gpu: every implicit-GEMM kernel variant, pinned per layer (ta_op_desc.variant), on layers of the sizes bench.py
+and the BASELINE configs run (C4: 16x46x82 maps, C5: 32x23x40 maps, C3: 256 crops), against torch-CPU conv2d fed with the
+very activations the kernel consumed (the producing layer's output read back through the debug tap).
+
+`ctx.conv_counts()` proves which kernel ran.  Errors are reported relative to max|reference| and bounded at ~10x what
+the kernels measure: f32 = exact-f32 MFMA (only the summation order differs from torch), bf16x3 drops the lo*lo term.
+DESIGN.md section 4 maps each variant to the test ids of this file.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from terran_amd import pack, synth
+
+pytestmark = pytest.mark.gpu
+
+# measured (MI355X, this file): f32 <= 4e-7, bf16x3 <= 9e-6 of max|ref|
+TOL = {'f32': 4e-6, 'bf16x3': 8e-5}
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from terran_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+LAYERS = {
+    # OpenPose stage conv Mconv1 at C4 size: 7x7, 185 (padded 192) -> 128, 16 x 46 x 82 maps        (model.py:58-95)
+    'pose7x7_192to128_c4': dict(n=16, h=46, w=82, c1=192, cout=128, k=7),
+    # the same layer at the 1080p size of bench.py (32 x 23 x 40 maps)
+    'pose7x7_192to128_c5': dict(n=32, h=23, w=40, c1=192, cout=128, k=7),
+    # PAF | heat-map branch pair as ONE grouped conv (pack.pack_openpose), C5 and C4 sizes
+    'pose7x7_grouped_c5': dict(n=32, h=23, w=40, c1=256, cout=256, k=7, groups=2),
+    'pose7x7_grouped_c4': dict(n=16, h=46, w=82, c1=256, cout=256, k=7, groups=2),
+    # ArcFace stage 3 body conv at C3 size: 3x3 256 -> 256, 256 crops x 14 x 14                      (arcface/model.py:11-35)
+    'arc3x3_256_c3': dict(n=256, h=14, w=14, c1=256, cout=256, k=3),
+    # ArcFace unit-closing conv: stride 2, PReLU-free, residual + next unit's BatchNorm as second output
+    'arc3x3_s2_res_out2': dict(n=64, h=56, w=56, c1=128, cout=128, k=3, stride=2, res=True, out2=True),
+    'arc3x3_prelu': dict(n=64, h=28, w=28, c1=128, cout=128, k=3, act=2),
+    # OpenPose VGG conv1_2 at the 1080p size: 3x3 64 -> 64 on 184 x 327 maps                           (model.py:41-57)
+    'vgg3x3_64_c5': dict(n=8, h=184, w=327, c1=64, cout=64, k=3, act=1),
+    # OpenPose stage output conv: 1x1 128 -> 38 into a channel slice of the 192-channel concat tensor
+    'pose1x1_to_slice': dict(n=16, h=46, w=82, c1=128, cout=38, k=1, out_total=192, out_off=128, cout_p=40),
+}
+
+CASES = [
+    # (layer, variant, mid tensor pinned to float32?)
+    ('pose7x7_192to128_c4', 'split_2x2', False), ('pose7x7_192to128_c4', 'split_2x4', False),
+    ('pose7x7_192to128_c4', 'split_2x2_p8', False), ('pose7x7_192to128_c4', 'split_1x4', False),
+    ('pose7x7_192to128_c4', 'pipe64', False), ('pose7x7_192to128_c4', 'pipe64', True),
+    ('pose7x7_192to128_c4', 'pipe128', True), ('pose7x7_192to128_c4', 'generic', True),
+    ('pose7x7_192to128_c5', 'split_2x2', False), ('pose7x7_192to128_c5', 'split_2x4', False),
+    ('pose7x7_192to128_c5', 'auto', False),
+    ('pose7x7_grouped_c5', 'split_2x4', False), ('pose7x7_grouped_c5', 'split_2x2', False),
+    ('pose7x7_grouped_c5', 'split_1x4', False), ('pose7x7_grouped_c5', 'auto', False),
+    ('pose7x7_grouped_c4', 'split_2x4', False), ('pose7x7_grouped_c4', 'auto', False),
+    ('arc3x3_256_c3', 'split_2x2', False), ('arc3x3_256_c3', 'split_2x4', False), ('arc3x3_256_c3', 'pipe64', False),
+    ('arc3x3_256_c3', 'auto', False),
+    ('arc3x3_s2_res_out2', 'split_2x2', False), ('arc3x3_s2_res_out2', 'split_2x4', False),
+    ('arc3x3_s2_res_out2', 'pipe64', True), ('arc3x3_s2_res_out2', 'generic', True),
+    ('arc3x3_prelu', 'split_2x4', False), ('arc3x3_prelu', 'auto', False),
+    ('vgg3x3_64_c5', 'split_1x4', False), ('vgg3x3_64_c5', 'pipe64', False), ('vgg3x3_64_c5', 'auto', False),
+    ('pose1x1_to_slice', 'generic', True), ('pose1x1_to_slice', 'auto', False),
+]
+
+_ref_cache = {}
+
+
+def _weights(L, rng):
+    c1, cout, k, groups = L['c1'], L['cout'], L['k'], L.get('groups', 1)
+    W1 = rng.normal(0, 0.3, (c1, 3, 3, 3)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, c1).astype(np.float32)
+    W2 = rng.normal(0, 1.0 / np.sqrt(c1 // groups * k * k), (cout, c1 // groups, k, k)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, cout).astype(np.float32)
+    return W1, b1, W2, b2
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('layer,variant,mid_f32', CASES, ids=['%s-%s%s' % (a, b, '-f32in' if c else '') for a, b, c in CASES])
+def test_conv_variant_at_bench_size(ctx, layer, variant, mid_f32, precision):
+    from terran_amd import lib
+    L = LAYERS[layer]
+    rng = np.random.default_rng(11)
+    n, h, w, c1, cout, k = L['n'], L['h'], L['w'], L['c1'], L['cout'], L['k']
+    stride, groups, act = L.get('stride', 1), L.get('groups', 1), L.get('act', 0)
+    out_off, out_total = L.get('out_off', 0), L.get('out_total', cout)
+    W1, b1, W2, b2 = _weights(L, rng)
+    P = pack.Program(pack.MODEL_OPENPOSE, precision)
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    t1 = P.tensor(c1, k // 2, name='mid', f32=mid_f32)
+    P.conv(t0, t1, W1, b1, act=pack.ACT_RELU)
+    t2 = P.tensor(out_total, 0, name='out', f32=True)
+    kw = dict(variant=lib.CONV_VARIANTS[variant], groups=groups)
+    prelu = scale2 = shift2 = Wr = br = None
+    if act == 2:
+        prelu = rng.uniform(0.1, 0.4, cout).astype(np.float32)
+        kw['prelu'] = prelu
+    if L.get('res'):
+        tres = P.tensor(cout, 0, name='res', f32=True)
+        Wr = rng.normal(0, 0.3, (cout, 3, 3, 3)).astype(np.float32)
+        br = rng.normal(0, 0.1, cout).astype(np.float32)
+        P.conv(t0, tres, Wr, br, stride=stride, pad=1)
+        kw['res'] = tres
+    if L.get('out2'):
+        t3 = P.tensor(cout, 1, name='out2', f32=True)
+        scale2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift2 = rng.normal(0, 0.2, cout).astype(np.float32)
+        kw.update(out2=t3, scale2=scale2, shift2=shift2)
+    P.conv(t1, t2, W2, b2, stride=stride, act=act, out_ch_off=out_off, cout_p=L.get('cout_p'), **kw)
+    P.outputs = [t2]
+    m = lib.Model(ctx, P)
+    images = synth.frames(5, n, h, w)
+    fr = ctx.upload(images)
+    ctx.conv_counts(reset=True)
+    m.forward_frames(fr)
+    counts = ctx.conv_counts()
+    if variant != 'auto':
+        assert counts.get(variant, 0) == 1, counts                    # the pinned kernel is the one that ran
+    mid = torch.from_numpy(m.read('mid'))                             # exactly what the conv under test consumed
+    key = (layer, precision, mid_f32)
+    if key not in _ref_cache:
+        y = F.conv2d(mid, torch.from_numpy(W2), torch.from_numpy(b2), stride=stride, padding=k // 2, groups=groups)
+        if act == 1:
+            y = F.relu(y)
+        elif act == 2:
+            y = F.prelu(y, torch.from_numpy(prelu))
+        if L.get('res'):
+            y = y + torch.from_numpy(m.read('res'))
+        _ref_cache[key] = (mid.numpy().copy(), y.numpy())
+    mid_ref, y = _ref_cache[key]
+    assert np.array_equal(mid.numpy(), mid_ref)                       # same input as the cached reference saw
+    scale = float(np.abs(y).max())
+    got = m.read('out')
+    err = float(np.abs(got[:, out_off:out_off + cout] - y).max()) / scale
+    print('%s %s %s: kernels %s, max err %.2e of max|ref|' % (layer, variant, precision, counts, err))
+    assert err <= TOL[precision], err
+    if out_total != cout:
+        mask = np.ones(out_total, bool)
+        mask[out_off:out_off + cout] = False
+        assert np.all(got[:, mask] == 0.0), 'conv wrote outside its channel slice'
+    if L.get('out2'):
+        z = y * scale2[None, :, None, None] + shift2[None, :, None, None]
+        assert float(np.abs(m.read('out2') - z).max()) / scale <= TOL[precision]
+    m.free()
+    fr.free()
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('variant', ['auto', 'split_2x2', 'split_1x4', 'pipe64'])
+def test_fc_25088_to_512_at_c3_size(ctx, variant, precision):
+    """ArcFace's Flatten + Linear 25088 -> 512 (arcface/model.py:79-85) as the 1x1 conv over the (N,1,1,25088) view, 256
+    crops: the K-split path (32 fixed K ranges + ordered reduction) under `auto` / split variants, one pass under pipe64."""
+    from terran_amd import lib
+    rng = np.random.default_rng(12)
+    n = 256
+    P = pack.Program(pack.MODEL_OPENPOSE, precision)
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    Z = P.tensor(512, 0, name='z')
+    W1 = rng.normal(0, 0.3, (512, 3, 3, 3)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, 512).astype(np.float32)
+    P.conv(t0, Z, W1, b1, act=pack.ACT_RELU)
+    A = P.tensor(7 * 7 * 512, 0, alias_of=Z)
+    Wl = rng.normal(0, 1.0 / np.sqrt(25088), (512, 25088)).astype(np.float32)
+    bl = rng.normal(0, 0.1, 512).astype(np.float32)
+    f = np.arange(7 * 7 * 512)
+    ch_pos = (f % 49) * 512 + f // 49                               # (C,H,W) flatten order -> NHWC position
+    E = P.tensor(512, 0, name='emb', f32=True)
+    P.conv(A, E, Wl.reshape(512, 25088, 1, 1), bl, ch_pos=ch_pos, pad=0, variant=lib.CONV_VARIANTS[variant])
+    P.outputs = [E]
+    m = lib.Model(ctx, P)
+    fr = ctx.upload(synth.frames(6, n, 7, 7))
+    ctx.conv_counts(reset=True)
+    m.forward_frames(fr)
+    counts = ctx.conv_counts()
+    z = m.read('z')                                                  # (n,512,7,7)
+    ref = z.reshape(n, -1).astype(np.float64) @ Wl.astype(np.float64).T + bl
+    got = m.read('emb')[:, :, 0, 0]
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    print('fc %s %s: kernels %s, max err %.2e of max|ref|' % (variant, precision, counts, err))
+    assert err <= TOL[precision], err
+    if variant != 'auto':
+        assert counts.get(variant, 0) == 1, counts
+    # batch composition must not change a single bit (fixed K ranges): the first 100 crops alone
+    fr2 = ctx.upload(synth.frames(6, n, 7, 7)[:100])
+    m.forward_frames(fr2)
+    assert np.array_equal(m.read('emb')[:, :, 0, 0], got[:100])
+    m.free()
+
+
+def test_pinned_variant_that_cannot_run_the_layer_is_an_error(ctx):
+    from terran_amd import lib
+    rng = np.random.default_rng(1)
+    P = pack.Program(pack.MODEL_OPENPOSE, 'f32')
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    t1 = P.tensor(16, 0, name='out')
+    P.conv(t0, t1, rng.normal(0, 0.3, (16, 3, 3, 3)).astype(np.float32), np.zeros(16, np.float32),
+           variant=lib.CONV_VARIANTS['split_2x4'])                  # Cin = 4: only the table-driven kernel can
+    P.outputs = [t1]
+    m = lib.Model(ctx, P)
+    with pytest.raises(lib.TerranAmdError) as e:
+        m.forward_frames(ctx.upload(synth.frames(1, 1, 16, 16)))
+    assert e.value.code == lib.E_INVALID and 'variant' in str(e.value)
