@@ -10,13 +10,15 @@ import importlib
 import os
 from pathlib import Path
 
+# `alias` is the reference's ('gpu-realtime', terran/checkpoint.py:40,64,89), so every reference-valid call such as
+# Detection(checkpoint='gpu-realtime') keeps working; 'mi355x-realtime' is an additional name for the same entry.
 CHECKPOINTS = [
-    {'id': 'b5d77fff', 'name': 'RetinaFace', 'task': 'face-detection',
-     'class': 'terran_amd.retinaface.RetinaFace', 'alias': 'mi355x-realtime', 'default': True, 'kind': 'retinaface'},
-    {'id': 'd206e4b0', 'name': 'ArcFace', 'task': 'face-recognition',
-     'class': 'terran_amd.arcface.ArcFace', 'alias': 'mi355x-realtime', 'default': True, 'kind': 'arcface'},
-    {'id': '11a769ad', 'name': 'OpenPose', 'task': 'pose-estimation',
-     'class': 'terran_amd.openpose.OpenPose', 'alias': 'mi355x-realtime', 'default': True, 'kind': 'openpose'},
+    {'id': 'b5d77fff', 'name': 'RetinaFace', 'task': 'face-detection', 'class': 'terran_amd.retinaface.RetinaFace',
+     'alias': 'gpu-realtime', 'aliases': ('mi355x-realtime',), 'default': True, 'kind': 'retinaface'},
+    {'id': 'd206e4b0', 'name': 'ArcFace', 'task': 'face-recognition', 'class': 'terran_amd.arcface.ArcFace',
+     'alias': 'gpu-realtime', 'aliases': ('mi355x-realtime',), 'default': True, 'kind': 'arcface'},
+    {'id': '11a769ad', 'name': 'OpenPose', 'task': 'pose-estimation', 'class': 'terran_amd.openpose.OpenPose',
+     'alias': 'gpu-realtime', 'aliases': ('mi355x-realtime',), 'default': True, 'kind': 'openpose'},
 ]
 
 
@@ -28,7 +30,7 @@ def get_checkpoint(task_name, alias):
     for c in CHECKPOINTS:
         if c['task'] != task_name:
             continue
-        if (alias is None and c['default']) or alias in (c['alias'], c['id']):
+        if (alias is None and c['default']) or alias in (c['alias'], c['id']) + tuple(c.get('aliases', ())):
             return c
     return None
 

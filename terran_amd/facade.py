@@ -61,8 +61,8 @@ class Detection:
         """-> (lib.Frames at network resolution, scale).  `image_batch` may already be resident."""
         H, W = image_batch.shape[1:3]
         scale = self.short_side / min(H, W)
-        if isinstance(image_batch, lib.Frames):
-            return image_batch.resize(int(H * scale), int(W * scale)), scale
+        if isinstance(image_batch, lib.Frames):           # possibly another thread's batch: read it, run on OUR context
+            return image_batch.resize(int(H * scale), int(W * scale), ctx=ctx), scale
         src = ctx.upload(image_batch)
         try:
             return src.resize(int(H * scale), int(W * scale)), scale

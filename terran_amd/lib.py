@@ -251,15 +251,19 @@ class Frames:
         ctx.check(ctx.lib.ta_frames_alloc(ctx.h, n, h, w, C.byref(hd)))
         return cls(ctx, handle=hd)
 
-    def resize(self, h, w):
+    def resize(self, h, w, ctx=None):
+        """`ctx`: the context (stream, scratch) the resize runs on and the result belongs to -- the CALLER's, so that a
+        batch handed over by another thread's context (video.RawVideoReader) is only ever read here, never driven."""
+        ctx = ctx or self.ctx
         hd = c_void_p()
-        self.ctx.check(self.ctx.lib.ta_frames_resize(self.ctx.h, self.h, int(h), int(w), C.byref(hd)))
-        return Frames(self.ctx, handle=hd)
+        ctx.check(ctx.lib.ta_frames_resize(ctx.h, self.h, int(h), int(w), C.byref(hd)))
+        return Frames(ctx, handle=hd)
 
-    def resize_bicubic(self, h, w):
+    def resize_bicubic(self, h, w, ctx=None):
+        ctx = ctx or self.ctx
         hd = c_void_p()
-        self.ctx.check(self.ctx.lib.ta_frames_resize_bicubic(self.ctx.h, self.h, int(h), int(w), C.byref(hd)))
-        return Frames(self.ctx, handle=hd)
+        ctx.check(ctx.lib.ta_frames_resize_bicubic(ctx.h, self.h, int(h), int(w), C.byref(hd)))
+        return Frames(ctx, handle=hd)
 
     def paste(self, src, src_index, dst_index, top, left):
         self.ctx.check(self.ctx.lib.ta_frames_paste(self.ctx.h, src.h, src_index, self.h, dst_index, top, left))

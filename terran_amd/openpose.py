@@ -45,7 +45,7 @@ class OpenPose:
             return []
         scale = self.short_side / min(H, W)
         nw, nh = int(W * scale), int(H * scale)                  # openpose/wrapper.py:95-99
-        resized = frames if (nh, nw) == (H, W) else frames.resize(nh, nw)
+        resized = frames if (nh, nw) == (H, W) else frames.resize(nh, nw, ctx=self.ctx)
         try:
             return _run(self.ctx, lambda cap, *a: self.ctx.lib.ta_openpose_run(
                 self.model.h, resized.h, float(scale), cap, *a), n)

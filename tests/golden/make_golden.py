@@ -147,8 +147,36 @@ def main():
          note='reference OpenPose.call with the model replaced by synth.pose_maps_batch(seed,2,P,h,w); '
               'input frames are (8h,8w) zeros so the cv2 shim is an identity')
 
-    # scale != 1: 1-image 64x96 frames at short_side=32 with the real net (crosses cv2 shim)
-    PW.load_model = lambda: _load(PM.BodyPoseModel, st_p)
+    # adversarial maps (noise-free): exact plateaus, exact score ties, coincident peaks / zero-length limbs
+    adv = {}
+    adv_cases = [('plateau', 3, 20, 28), ('plateau', 4, 23, 40), ('twins', 3, 20, 28), ('twins', 5, 23, 40),
+                 ('coincident', 3, 20, 28), ('coincident', 6, 23, 40)]
+    for kind, seed, h, w in adv_cases:
+        hmap, pafs = synth.pose_maps_adversarial(kind, seed, h, w)
+        PW.load_model = lambda: Fake(torch.from_numpy(pafs[None]), torch.from_numpy(hmap[None]))
+        m = PW.OpenPose(device=tdev, short_side=8 * h)
+        c, kp, sc = flat_poses(m.call(np.zeros((1, 8 * h, 8 * w, 3), np.uint8)))
+        key = '%s_%d' % (kind, seed)
+        adv[key + '_counts'], adv[key + '_keypoints'], adv[key + '_scores'] = c, kp, sc
+    save('openpose_adversarial.npz', cases=np.array([(k, str(s), str(h), str(w)) for k, s, h, w in adv_cases]), **adv,
+         note='reference OpenPose.call with the model replaced by synth.pose_maps_adversarial(kind, seed, h, w)')
+
+    # ---- end to end with the DECODER weights: frames that carry pose maps -> non-empty humans --------------
+    st_d = weights.make_openpose_decoder_state()
+    PW.load_model = lambda: _load(PM.BodyPoseModel, st_d)
+    e2e = {}
+    m = PW.OpenPose(device=tdev, short_side=96)
+    coded = synth.pose_code_frames(60, 2, 96, 128, 3)
+    e2e['a_counts'], e2e['a_keypoints'], e2e['a_scores'] = flat_poses(m.call(coded))             # scale 1
+    big = synth.upscale_for_resize(coded, 288, 384)
+    e2e['b_counts'], e2e['b_keypoints'], e2e['b_scores'] = flat_poses(m.call(big))                # scale 1/3 (cv2 shim)
+    m184 = PW.OpenPose(device=tdev, short_side=184)
+    hd = synth.upscale_for_resize(synth.pose_code_frames(61, 1, 184, 327, 4), 1080, 1920)
+    e2e['c_counts'], e2e['c_keypoints'], e2e['c_scores'] = flat_poses(m184.call(hd))              # 1080p -> 184 x 327
+    save('openpose_e2e.npz', **e2e,
+         note='reference OpenPose.call, weights.make_openpose_decoder_state(): a = pose_code_frames(60,2,96,128,3) at '
+              'short_side 96; b = the same upscaled to 288x384 (upscale_for_resize; crosses the cv2 shim); c = '
+              'pose_code_frames(61,1,184,327,4) upscaled to 1080x1920 at short_side 184')
 
     # ------------------------------------------------------------------ bicubic
     m = np.random.default_rng(4).normal(0, 1, (1, 8, 6, 7)).astype(np.float32)
@@ -201,14 +229,29 @@ def main():
          note='reference Detection(short_side=208)(frames(0,1,480,640)[0]) and on the list '
               '[frame[:400,:500], frame]; crosses the cv2.resize shim (oracle.facade.cv2_resize_linear)')
 
-    # pose facade: real net at small scale, list input (pad merge + un-pad)
+    # pose facade, random-weight net (no person assembles: the empty path), list input, crosses the cv2 shim
+    PW.load_model = lambda: _load(PM.BodyPoseModel, st_p)
     e = FP.Estimation(short_side=64, device=tdev)
     f2 = synth.frames(7, 1, 96, 128)[0]
     pr = e([f2[:80, :100], f2])
     c, kp, sc = flat_poses(pr)
+    # pose facade with the decoder weights: non-empty results through pad-merge (odd pads: ceil top/left), un-pad and
+    # the present == 0 reset (pose/__init__.py:94-122); single image; ndarray batch with a resize
+    PW.load_model = lambda: _load(PM.BodyPoseModel, st_d)
+    e = FP.Estimation(short_side=96, device=tdev)
+    coded = synth.pose_code_frames(62, 2, 96, 128, 3)
+    lst = e([coded[0][9:88, 14:115], coded[1]])             # 79 x 101 inside 96 x 128: pads (9, 8) x (14, 13)
+    lc, lkp, lsc = flat_poses(lst)
+    one = e(coded[1])
+    oc, okp, osc = flat_poses([one])
+    big = synth.upscale_for_resize(coded, 288, 384)
+    bc, bkp, bsc = flat_poses(e(big))
     save('facade_pose.npz', frame_seed=7, counts=c, keypoints=kp, scores=sc,
-         note='reference Estimation(short_side=64) on list [frames(7,1,96,128)[0][:80,:100], same full]; '
-              'random-weight net; crosses the cv2 shim')
+         l_counts=lc, l_keypoints=lkp, l_scores=lsc, o_counts=oc, o_keypoints=okp, o_scores=osc,
+         b_counts=bc, b_keypoints=bkp, b_scores=bsc,
+         note='reference Estimation: (counts..) short_side=64 on list [frames(7,1,96,128)[0][:80,:100], same full], '
+              'random-weight net; l_* = Estimation(short_side=96), decoder weights, list [pose_code_frames(62,2,96,128,3)'
+              '[0][9:88,14:115], [1]]; o_* = single image [1]; b_* = the batch upscaled to 288x384 (cv2 shim)')
 
     # recognition facade rank handling
     rec = FR.Recognition(device=tdev)

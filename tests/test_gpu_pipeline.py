@@ -231,6 +231,93 @@ def test_openpose_call_vs_oracle(pose, states):
             np.testing.assert_allclose(a['score'], b['score'], rtol=1e-3)
 
 
+def _flat(poses):
+    kp = np.array([o['keypoints'] for p in poses for o in p], np.int32).reshape(-1, 18, 3)
+    sc = np.array([o['score'] for p in poses for o in p], np.float64)
+    return [len(p) for p in poses], kp, sc
+
+
+def _assert_stage_taps_equal(ctx, n, hm, paf, scale=1.0):
+    """Device peaks / connections of the LAST grouping on `ctx` == the oracle's on the same network-resolution maps."""
+    from oracle import openpose_post
+    peaks, conns = ctx.pose_debug(n)
+    hm_up, paf_up = openpose_post.bicubic_x8(hm), openpose_post.bicubic_x8(paf)
+    n_peaks = n_conn = 0
+    for i in range(n):
+        dbg = {}
+        openpose_post.group_image(hm_up[i], paf_up[i], scale, dbg)
+        for part in range(18):
+            locs, scs = dbg['peaks'][part]
+            assert np.array_equal(peaks[i][part][0], locs.astype(np.int32)), ('peaks', i, part)
+            assert np.array_equal(peaks[i][part][1], scs), ('peak scores', i, part)
+            n_peaks += len(scs)
+        for limb in range(19):
+            ref = dbg['connections'][limb]
+            got = conns[i][limb]
+            if ref is None:
+                assert got is None, ('limb should be skipped', i, limb)
+                continue
+            assert got is not None and len(got[1]) == len(ref), ('connections', i, limb)
+            for k, (a, b, sc) in enumerate(ref):
+                assert (int(got[0][k, 0]), int(got[0][k, 1])) == (a, b) and got[1][k] == sc, ('connection', i, limb, k)
+            n_conn += len(ref)
+    return n_peaks, n_conn
+
+
+def test_openpose_group_adversarial_vs_reference(ctx):
+    """Noise-free maps with exact plateaus (`>=` yields several peaks, one exactly at the 0.1 threshold), exact score
+    ties in every limb's candidate sort and coincident peaks of different parts (zero-length limbs, NaN scores):
+    humans == the REFERENCE wrapper's, and every intermediate (peaks, accepted connections) == the oracle's."""
+    from terran_amd import openpose
+    g = golden('openpose_adversarial.npz')
+    for kind, seed, h, w in g['cases']:
+        hm, paf = synth.pose_maps_adversarial(str(kind), int(seed), int(h), int(w))
+        c, kp, sc = _flat(openpose.group(ctx, paf[None], hm[None], 1.0))
+        key = '%s_%s' % (kind, seed)
+        assert c == g[key + '_counts'].tolist()
+        assert np.array_equal(kp, g[key + '_keypoints'])
+        np.testing.assert_allclose(sc, g[key + '_scores'], rtol=1e-6)
+        n_peaks, n_conn = _assert_stage_taps_equal(ctx, 1, hm[None], paf[None])
+        assert n_peaks >= 36 and n_conn >= 30
+
+
+def test_openpose_stage_taps_on_the_nets_own_maps(pose, states):
+    """The seam net -> x8 bicubic -> peaks -> PAF scoring -> matching on the RANDOM-weight network's own output: the
+    device's maps are read back and pushed through the oracle, whose peaks and connections must equal the device's
+    (hundreds of peaks and dozens of accepted connections per frame, though no person assembles)."""
+    frames = synth.frames(7, 2, 96, 128)
+    out = pose.call(frames)                                   # short_side 64 -> 64 x 85 input, 8 x 10 maps
+    hm, paf = pose.model.read('heatmaps'), pose.model.read('pafs')
+    n_peaks, n_conn = _assert_stage_taps_equal(pose.ctx, 2, hm, paf, scale=64 / 96)
+    print('random net: %d peaks, %d connections, %d humans' % (n_peaks, n_conn, sum(len(p) for p in out)))
+    assert n_peaks > 50
+
+
+def test_openpose_call_end_to_end_vs_reference(states, precision):
+    """Frames that carry pose maps + decoder weights (terran_amd/weights.py): the whole wrapper (device resize, net,
+    x8 bicubic, peaks, limbs, assembly) returns the REFERENCE's humans -- non-empty, keypoints exact -- at scale 1,
+    through a 1/3 resize, and for a 1080p frame at the default short_side 184."""
+    from terran_amd import OpenPose
+    g = golden('openpose_e2e.npz')
+    sd = states('openpose_decoder')
+    pose96 = OpenPose(device=0, short_side=96, state=sd, precision=precision)
+    coded = synth.pose_code_frames(60, 2, 96, 128, 3)
+    for tag, frames in (('a', coded), ('b', synth.upscale_for_resize(coded, 288, 384))):
+        c, kp, sc = _flat(pose96.call(frames))
+        assert c == g[tag + '_counts'].tolist() and sum(c) >= 6
+        assert np.array_equal(kp, g[tag + '_keypoints'])
+        np.testing.assert_allclose(sc, g[tag + '_scores'], rtol=2e-4)
+    # the net's maps of the last call vs the oracle's stages, too
+    hm, paf = pose96.model.read('heatmaps'), pose96.model.read('pafs')
+    _assert_stage_taps_equal(pose96.ctx, 2, hm, paf, scale=1 / 3)
+    pose184 = OpenPose(device=0, short_side=184, state=sd, precision=precision)
+    hd = synth.upscale_for_resize(synth.pose_code_frames(61, 1, 184, 327, 4), 1080, 1920)
+    c, kp, sc = _flat(pose184.call(hd))
+    assert c == g['c_counts'].tolist() and c[0] >= 3
+    assert np.array_equal(kp, g['c_keypoints'])
+    np.testing.assert_allclose(sc, g['c_scores'], rtol=2e-4)
+
+
 # ---- frames ----------------------------------------------------------------------------------
 def test_frames_resize_and_paste(ctx):
     from oracle import facade, arcface_pre
@@ -284,6 +371,19 @@ def test_facade_pose_and_recognition_vs_reference(states, precision):
     np.testing.assert_allclose([o['score'] for p in res for o in p], g['scores'], rtol=1e-3)
     single = e(f2)
     assert isinstance(single, list) and (not single or isinstance(single[0], dict))
+    # non-empty results (decoder weights + frames that carry pose maps): odd pads (ceil top / left), un-pad,
+    # present == 0 rows reset (pose/__init__.py:94-122); single image; ndarray batch through the resize
+    e = Estimation(short_side=96, device=0, state=states('openpose_decoder'), precision=precision)
+    coded = synth.pose_code_frames(62, 2, 96, 128, 3)
+    c, kp, sc = _flat(e([coded[0][9:88, 14:115], coded[1]]))
+    assert c == g['l_counts'].tolist() and sum(c) >= 4
+    assert np.array_equal(kp, g['l_keypoints'])
+    np.testing.assert_allclose(sc, g['l_scores'], rtol=2e-4)
+    assert (kp[..., 2] == 0).any() and np.all(kp[kp[..., 2] == 0] == 0)
+    one = e(coded[1])
+    assert isinstance(one[0], dict) and np.array_equal(_flat([one])[1], g['o_keypoints'])
+    c, kp, sc = _flat(e(synth.upscale_for_resize(coded, 288, 384)))
+    assert c == g['b_counts'].tolist() and np.array_equal(kp, g['b_keypoints'])
 
     g = golden('facade_recognition.npz')
     a = golden('arcface_call.npz')
@@ -298,6 +398,54 @@ def test_facade_pose_and_recognition_vs_reference(states, precision):
     assert many[1].shape == (0, 512) and str(many[1].dtype) == str(g['many1_dtype'])
     with pytest.raises(ValueError):
         rec([image, image], [[]])
+
+
+# ---- registry -> <id>.pth -> repack cache -> device (terran/checkpoint.py:213-245, 277-328) ----------------------
+def test_registry_checkpoint_files_cold_and_warm(states, precision, tmp_path, monkeypatch):
+    """The real drop-in path: no `state=`; the facades resolve the class through the registry (default entry, the
+    reference's alias 'gpu-realtime', the id), read `$TERRAN_HOME/checkpoints/<id>.pth` (a torch-saved state_dict, as
+    Terran's downloader leaves it), repack it and cache the packed program next to it (.tam).  Cold (pack + write) and
+    warm (read the cache) constructions must give bit-identical results to the `state=dict` path."""
+    from terran_amd import Detection, Recognition, Estimation, checkpoint
+    monkeypatch.setenv('TERRAN_HOME', str(tmp_path))
+    monkeypatch.delenv('TERRAN_AMD_NO_PACK_CACHE', raising=False)
+    ck = tmp_path / 'checkpoints'
+    ck.mkdir()
+    kinds = {'b5d77fff': 'retinaface', 'd206e4b0': 'arcface', '11a769ad': 'openpose_decoder'}
+    for cid, kind in kinds.items():
+        torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in states(kind).items()}, str(ck / (cid + '.pth')))
+    frame = synth.frames(0, 1, 240, 320)[0]
+    pframes = synth.pose_code_frames(60, 2, 96, 128, 3)
+    lms = [{'landmarks': l} for l in synth.landmarks(1, 2, 240, 320)]
+
+    def run(det, rec, est):
+        return det(frame), rec(frame, lms), est(pframes)
+    want = run(Detection(short_side=128, device=0, state=states('retinaface'), precision=precision),
+               Recognition(device=0, state=states('arcface'), precision=precision),
+               Estimation(short_side=96, device=0, state=states('openpose_decoder'), precision=precision))
+    assert len(want[0]) > 0 and sum(len(p) for p in want[2]) >= 6
+    stamps = None
+    for alias in (None, 'gpu-realtime', 'b5d77fff'):                     # cold, warm, warm
+        got = run(Detection(checkpoint=alias, short_side=128, device=0, precision=precision),
+                  Recognition(checkpoint=alias if alias != 'b5d77fff' else 'd206e4b0', device=0, precision=precision),
+                  Estimation(checkpoint=alias if alias != 'b5d77fff' else '11a769ad', short_side=96, device=0,
+                             precision=precision))
+        for a, b in zip(got[0], want[0]):
+            assert all(np.array_equal(a[k], b[k]) for k in ('bbox', 'landmarks', 'score'))
+        assert np.array_equal(got[1], want[1])
+        assert _flat(got[2])[0] == _flat(want[2])[0] and np.array_equal(_flat(got[2])[1], _flat(want[2])[1])
+        assert np.array_equal(_flat(got[2])[2], _flat(want[2])[2])
+        tams = sorted(ck.glob('*.%s.*.tam' % precision))
+        assert len(tams) == 3                                             # one packed program per checkpoint
+        now = [t.stat().st_mtime_ns for t in tams]
+        assert stamps is None or now == stamps                            # warm constructions do not repack
+        stamps = now
+    with pytest.raises(ValueError, match='Checkpoint not found'):
+        Detection(checkpoint='no-such-alias', device=0)
+    assert checkpoint.get_class_for_checkpoint('pose-estimation', 'mi355x-realtime').__name__ == 'OpenPose'
+    (ck / 'd206e4b0.pth').unlink()
+    with pytest.raises(ValueError, match='Checkpoint not found'):          # weights file absent (terran/checkpoint.py:310)
+        Recognition(device=0, precision=precision)
 
 
 # ---- plan cache / video reader --------------------------------------------------------------------
