@@ -15,8 +15,8 @@ from terran_amd import pack, synth
 
 pytestmark = pytest.mark.gpu
 
-# measured (MI355X, this file): f32 <= 4e-7, bf16x3 <= 9e-6 of max|ref|
-TOL = {'f32': 4e-6, 'bf16x3': 8e-5}
+# measured (MI355X, this file): f32 <= 3.7e-6 (K = 9408 products per output: summation order), bf16x3 <= 5.6e-6 of max|ref|
+TOL = {'f32': 2e-5, 'bf16x3': 5e-5}
 
 
 @pytest.fixture(scope='module')
@@ -118,8 +118,9 @@ def test_conv_variant_at_bench_size(ctx, layer, variant, mid_f32, precision):
     ctx.conv_counts(reset=True)
     m.forward_frames(fr)
     counts = ctx.conv_counts()
-    if variant != 'auto':
-        assert counts.get(variant, 0) == 1, counts                    # the pinned kernel is the one that ran
+    if variant != 'auto':                                             # the pinned kernel is the one that ran
+        helpers = 1 + (1 if L.get('res') else 0)                      # the 3 -> c1 stem (and the residual's producer) are `generic`
+        assert counts.get(variant, 0) == (1 + helpers if variant == 'generic' else 1), counts
     mid = torch.from_numpy(m.read('mid'))                             # exactly what the conv under test consumed
     key = (layer, precision, mid_f32)
     if key not in _ref_cache:

@@ -1,7 +1,9 @@
 """-m gpu: the three networks on the HIP path (through the C ABI) against the oracle.
 
-Float tolerance: rtol = atol = 1e-3 (BASELINE.json north_star: "within 1e-3 fp32"),
-scaled by the tensor's magnitude for un-normalised embeddings.
+BASELINE.json's bar is "within 1e-3 fp32"; these tests hold the kernels to ~10x the error they actually measure
+(relative to max|reference| of each tensor): f32 = exact-f32 MFMA, only the summation order differs from torch
+(measured <= 3e-6 after ~100 layers); bf16x3 drops the lo*lo product terms (measured <= 2.3e-5).  Every comparison
+prints the error it achieved.
 """
 import numpy as np
 import pytest
@@ -21,22 +23,29 @@ def ctx():
     c.close()
 
 
-def _close(a, b, tol=1e-3, what=''):
+NET_TOL = {'f32': 3e-5, 'bf16x3': 2e-4}
+_prec = ['f32']
+
+
+def _close(a, b, tol=None, what=''):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
+    tol = NET_TOL[_prec[0]] if tol is None else tol
     scale = max(1.0, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())
     assert a.shape == b.shape, (what, a.shape, b.shape)
+    print('  %-16s max abs err %.2e / scale %.2e = %.2e (tol %.0e)' % (what, err, scale, err / scale, tol))
     assert err <= tol * scale, '%s: max abs err %.3e (scale %.3e)' % (what, err, scale)
     return err
 
 
-PRECISIONS = ['f32', 'bf16x3']      # both must meet the 1e-3 bar; 'bf16' (throughput mode) is not expected to
+PRECISIONS = ['f32', 'bf16x3']      # both parity-grade modes; 'bf16' (throughput mode) is not expected to pass
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_openpose_net(ctx, states, precision):
     from terran_amd import lib
+    _prec[0] = precision
     from oracle import nets
     sd = states('openpose')
     m = lib.Model(ctx, pack.pack_openpose(sd, precision))
@@ -65,6 +74,7 @@ def test_openpose_net(ctx, states, precision):
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_arcface_net(ctx, states, precision):
     from terran_amd import lib
+    _prec[0] = precision
     from oracle import nets
     sd = states('arcface')
     m = lib.Model(ctx, pack.pack_arcface(sd, precision))
@@ -85,6 +95,7 @@ def test_arcface_net(ctx, states, precision):
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_retinaface_net(ctx, states, precision):
     from terran_amd import lib
+    _prec[0] = precision
     from oracle import nets
     sd = states('retinaface')
     m = lib.Model(ctx, pack.pack_retinaface(sd, precision))

@@ -207,7 +207,11 @@ def test_pack_cache_roundtrip(tmp_path, states, monkeypatch):
     p2 = runtime.packed_program('retinaface', None, 'bf16x3')     # served from the cache
     assert p2.blob() == p1.blob() and p2.names == p1.names and p2.kind == pack.MODEL_RETINAFACE
     assert p1.blob() == pack.pack_retinaface(sd, 'bf16x3').blob()
-    p3 = runtime.packed_program('retinaface', None, 'f32')        # other precision: its own cache entry
-    assert p3.blob() != p1.blob() and len(list((tmp_path / 'checkpoints').glob('*.tam'))) == 2
+    p3 = runtime.packed_program('retinaface', None, 'f32')        # other precision: its own cache entry ...
+    assert len(list((tmp_path / 'checkpoints').glob('*.tam'))) == 2
+    assert p3.blob() == p1.blob()                                 # ... but the detector runs exact-f32 in both parity modes
+    assert pack.pack_retinaface(sd, 'bf16').blob() != p1.blob()
+    sa = states('arcface')
+    assert pack.pack_arcface(sa, 'f32').blob() != pack.pack_arcface(sa, 'bf16x3').blob()
     with pytest.raises(ValueError):
         runtime.resolve_state('openpose', None)                   # no file, no synthetic fallback
