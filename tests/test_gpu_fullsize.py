@@ -224,16 +224,28 @@ def test_c5_fullsize_frame_vs_oracle(states, precision):
     r_feats = pipeline.recognition(sd_a, frame, faces)
     r_poses = pipeline.estimation(sd_p, frame, short_side=184)
     assert len(dets) == len(r_dets) > 50
-    # integer coordinates: np.around(x / scale) turns a 1e-5 px difference into a whole pixel when x / scale sits on a
-    # half (about one coordinate in 10^4): at most 1 apart, and all but <= 0.1 % identical
-    got_i = np.array([np.concatenate([a['bbox'], a['landmarks'].ravel()]) for a in dets])
-    ref_i = np.array([np.concatenate([b['bbox'], b['landmarks'].ravel()]) for b in r_dets])
-    n_off = int((got_i != ref_i).sum())
-    assert np.abs(got_i - ref_i).max() <= 1 and n_off <= max(1, got_i.size // 1000), n_off
+    # Two float32 implementations of the same network agree to ~1e-6 in the scores, so
+    #  * detections whose scores tie within that may come out in swapped ORDER (this frame has ~370 detections with
+    #    densely packed scores): a position may hold the oracle's neighbour, only if their scores differ by < 1e-5;
+    #  * np.around(x / scale) turns a 1e-5 px difference into a whole pixel when x / scale sits on a half: integer
+    #    coordinates at most 1 apart, all but <= 0.1 % identical.
+    def vec(o):
+        return np.concatenate([o['bbox'], o['landmarks'].ravel()]).astype(np.int64)
+    n_swapped = n_off = 0
+    for i, a in enumerate(dets):
+        cand = [j for j in range(max(0, i - 3), min(len(r_dets), i + 4)) if np.abs(vec(a) - vec(r_dets[j])).max() <= 1]
+        assert cand, 'detection %d has no counterpart near its position in the oracle list' % i
+        j = i if i in cand else cand[0]
+        if j != i:
+            n_swapped += 1
+            assert abs(float(a['score']) - float(r_dets[i]['score'])) < 1e-5        # only near-tied scores trade places
+        n_off += int((vec(a) != vec(r_dets[j])).sum())
+    assert n_swapped <= max(2, len(dets) // 50) and n_off <= max(1, 14 * len(dets) // 1000), (n_swapped, n_off)
     err = float(np.abs(feats - r_feats).max())
     assert len(poses) == len(r_poses) >= 3
     for a, b in zip(poses, r_poses):
         assert np.array_equal(a['keypoints'], b['keypoints'])
-    print('C5 %s: %d detections in the order of the oracle, %d of %d integer coordinates off by one (rounding at .5), '
-          'embeddings max abs err %.2e, %d humans exact' % (precision, len(dets), n_off, got_i.size, err, len(poses)))
+    print('C5 %s: %d detections (%d near-tied scores in swapped order, %d of %d integer coordinates off by one at a '
+          'rounding half), embeddings max abs err %.2e, %d humans exact' %
+          (precision, len(dets), n_swapped, n_off, 14 * len(dets), err, len(poses)))
     assert err <= (5e-6 if precision == 'f32' else 5e-5)
