@@ -8,21 +8,24 @@ Generic pre-processing runs on the device (`ta_frames_resize` = cv2 INTER_LINEAR
 `ta_frames_paste` = zero pad-merge), so a batch of frames is uploaded once.
 """
 import math
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import lib
+from . import lib, runtime
 from .checkpoint import get_class_for_checkpoint
+from .shard import shard_bounds
 
 
 def _is_single(images):
     return not isinstance(images, (list, tuple)) and len(images.shape) == 3
 
 
-def _pads(shapes):
-    """Per image ((top,bottom),(left,right)) to the max size; the odd pixel goes top/left."""
-    mh = max(s[0] for s in shapes)
-    mw = max(s[1] for s in shapes)
+def _pads(shapes, canvas=None):
+    """Per image ((top,bottom),(left,right)) to the max size; the odd pixel goes top/left.
+    `canvas` = (mh, mw) of the WHOLE list when this call only sees a shard of it (`_Fanout`)."""
+    mh = max(s[0] for s in shapes) if canvas is None else canvas[0]
+    mw = max(s[1] for s in shapes) if canvas is None else canvas[1]
     pads = []
     for h, w in shapes:
         dh, dw = max(0, (mh - h) / 2), max(0, (mw - w) / 2)
@@ -30,19 +33,68 @@ def _pads(shapes):
     return mh, mw, pads
 
 
-def _merge(ctx, frame_list):
+def _merge(ctx, frame_list, canvas=None):
     """List of single-image lib.Frames -> one padded lib.Frames + pads."""
-    mh, mw, pads = _pads([f.shape[1:3] for f in frame_list])
+    mh, mw, pads = _pads([f.shape[1:3] for f in frame_list], canvas)
     canvas = lib.Frames.zeros(ctx, len(frame_list), mh, mw)
     for i, (f, p) in enumerate(zip(frame_list, pads)):
         canvas.paste(f, 0, i, p[0][0], p[1][0])
     return canvas, pads
 
 
+class _Fanout:
+    """SURVEY.md 8(e) inside ONE process: `device=[0, 1, ..., 7]` makes a facade a fan-out over one replica of itself
+    per listed device -- its own context (HIP stream, scratch, pinned staging) and weights, driven by its own host
+    thread.  A call cuts the frame batch (or list) into contiguous sub-batches, one per device (`shard.shard_bounds`:
+    video order is kept, sizes differ by at most one), every thread uploads and processes its sub-batch, and the
+    variable-length per-frame results are concatenated in device order on the calling thread.  Frames are independent
+    through the whole path: there is no collective, and the result equals the one-device result exactly.  The same
+    device may be listed more than once (several streams on one GPU)."""
+
+    def __init__(self, devices, make_replica):
+        self.devices = list(devices)
+        if not self.devices:
+            raise ValueError('`device` list is empty')
+        # replica 0 lives on the shared per-device context, further replicas (also on a repeated device) get their own
+        seen = set()
+        self.replicas = []
+        for d in self.devices:
+            idx = runtime.device_index(d)
+            ctx = runtime.get_context(idx) if idx not in seen else runtime.new_context(idx)
+            seen.add(idx)
+            self.replicas.append(make_replica(d, ctx))
+        self.pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix='terran_amd-device')
+
+    def __call__(self, items, *per_item, **kw):
+        """items: ndarray batch or list; per_item: sequences aligned with it (sharded the same way); kw: passed on."""
+        if isinstance(items, lib.Frames):
+            raise ValueError('a batch that is already resident on one device cannot be fanned out: pass host frames')
+        n = len(items)
+        k = len(self.replicas)
+        futs = []
+        for r, rep in enumerate(self.replicas):
+            lo, hi = shard_bounds(n, k, r)
+            if hi > lo:
+                futs.append(self.pool.submit(rep, items[lo:hi], *[p[lo:hi] for p in per_item], **kw))
+        out = []
+        for f in futs:                     # device order == frame order
+            out.extend(f.result())
+        return out
+
+
+def _is_device_list(device):
+    return isinstance(device, (list, tuple))
+
+
 class Detection:
 
     def __init__(self, checkpoint=None, short_side=416, merge_method='padding', device=None, lazy=False, **model_kw):
         self.device = device
+        self._fanout = None
+        if _is_device_list(device):
+            self._fanout = _Fanout(device, lambda d, ctx: Detection(checkpoint, short_side, merge_method, d, False,
+                                                                     ctx=ctx, **model_kw))
+            lazy = True
         self.detection_cls = get_class_for_checkpoint('face-detection', checkpoint)
         self.short_side = short_side
         if merge_method == 'crop':
@@ -69,10 +121,20 @@ class Detection:
         finally:
             src.free()
 
-    def __call__(self, images):
+    def __call__(self, images, _canvas=None):
         expanded = not isinstance(images, lib.Frames) and _is_single(images)
         if expanded:
             images = np.expand_dims(images, 0)
+        if self._fanout is not None:
+            kw = {}
+            if not isinstance(images, np.ndarray):                      # list: every shard pads to the WHOLE list's canvas
+                if self._merge_error is not None:
+                    raise self._merge_error
+                sizes = [(int(h * (self.short_side / min(h, w))), int(w * (self.short_side / min(h, w))))
+                         for h, w in (np.asarray(im).shape[:2] for im in images)]
+                kw['_canvas'] = (max(s[0] for s in sizes), max(s[1] for s in sizes))
+            out = self._fanout(images, **kw)
+            return out[0] if expanded else out
         if self.model is None:
             self.model = self.detection_cls(device=self.device, **self._model_kw)
         ctx = self.model.ctx
@@ -87,7 +149,7 @@ class Detection:
                 f, s = self._resized(ctx, np.asarray(im)[None])
                 singles.append(f)
                 scales.append(s)
-            frames, pads = _merge(ctx, singles)
+            frames, pads = _merge(ctx, singles, _canvas)
             for f in singles:
                 f.free()
         try:
@@ -117,6 +179,10 @@ class Recognition:
 
     def __init__(self, checkpoint=None, device=None, lazy=False, **model_kw):
         self.device = device
+        self._fanout = None
+        if _is_device_list(device):
+            self._fanout = _Fanout(device, lambda d, ctx: Recognition(checkpoint, d, False, ctx=ctx, **model_kw))
+            lazy = True
         self.recognition_cls = get_class_for_checkpoint('face-recognition', checkpoint)
         self._model_kw = model_kw
         self.model = None if lazy else self.recognition_cls(device=device, **model_kw)
@@ -133,8 +199,14 @@ class Recognition:
         if faces_per_image is not None and len(faces_per_image) != len(images):
             raise ValueError('`images` and `faces_per_image` must be of the same size, but the former is of size '
                              '%d while the latter of size %d.' % (len(images), len(faces_per_image)))
+        if self._fanout is not None and faces_per_image is not None:
+            out = self._fanout(list(images), list(faces_per_image))
+            if any(len(f) for f in faces_per_image):                    # a shard without faces answers float64 (0,512)
+                out = [o.astype(np.float32) if o.shape[0] == 0 else o for o in out]   # (wrapper.py:160-164); 1-way: float32
+            return out[0] if expanded else out
         if self.model is None:
-            self.model = self.recognition_cls(device=self.device, **self._model_kw)
+            self.model = self.recognition_cls(device=self.device if self._fanout is None else self.device[0],
+                                              **self._model_kw)
         out = self.model.call(images, faces_per_image)
         # the reference's `isinstance(faces_per_image, dict)` test (line 85) can never be true after the
         # re-binding above, so a single image + single dict yields (1,512); reproduced here.
@@ -145,6 +217,11 @@ class Estimation:
 
     def __init__(self, checkpoint=None, short_side=184, merge_method='padding', device=None, lazy=False, **model_kw):
         self.device = device
+        self._fanout = None
+        if _is_device_list(device):
+            self._fanout = _Fanout(device, lambda d, ctx: Estimation(checkpoint, short_side, merge_method, d, False,
+                                                                      ctx=ctx, **model_kw))
+            lazy = True
         self.estimation_cls = get_class_for_checkpoint('pose-estimation', checkpoint)
         self.short_side = short_side
         if merge_method == 'crop':
@@ -159,10 +236,19 @@ class Estimation:
     def __repr__(self):
         return '<Estimation(%s)>' % self.estimation_cls.__name__
 
-    def __call__(self, images):
+    def __call__(self, images, _canvas=None):
         expanded = not isinstance(images, lib.Frames) and _is_single(images)
         if expanded:
             images = np.expand_dims(images, 0)
+        if self._fanout is not None:
+            kw = {}
+            if not isinstance(images, np.ndarray):
+                if self._merge_error is not None:
+                    raise self._merge_error
+                sizes = [np.asarray(im).shape[:2] for im in images]
+                kw['_canvas'] = (max(s[0] for s in sizes), max(s[1] for s in sizes))
+            out = self._fanout(images, **kw)
+            return out[0] if expanded else out
         if self.model is None:
             self.model = self.estimation_cls(device=self.device, short_side=self.short_side, **self._model_kw)
         ctx = self.model.ctx
@@ -176,7 +262,7 @@ class Estimation:
             if self._merge_error is not None:
                 raise self._merge_error
             singles = [ctx.upload(np.asarray(im)[None]) for im in images]
-            frames, pads = _merge(ctx, singles)
+            frames, pads = _merge(ctx, singles, _canvas)
             for f in singles:
                 f.free()
         try:

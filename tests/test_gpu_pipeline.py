@@ -581,3 +581,53 @@ def test_pose_stats_follow_the_last_grouping(ctx):
     assert humans > 0 and peaks >= 4 * humans and conns >= 3 * humans      # a person needs >= 4 parts, >= 3 limbs
     openpose.group(ctx, np.zeros((1, 38, 6, 8), np.float32), np.zeros((1, 19, 6, 8), np.float32), 1.0)
     assert ctx.pose_stats() == (0, 0)
+
+
+# ---- single-process multi-device fan-out ---------------------------------------------------------
+def test_fanout_two_contexts_equal_one_way(states, precision):
+    """`device=[0, 0]`: two replicas (contexts, weights, host threads) on this one card stand in for two GPUs.  Detect +
+    embed + pose over an odd-sized batch, a list of differently sized images (pad-merge to the WHOLE list's canvas) and
+    a batch smaller than the device list must equal the one-device result exactly -- including non-empty poses."""
+    from terran_amd import Detection, Recognition, Estimation
+    kw = dict(precision=precision)
+    one = (Detection(short_side=128, device=0, state=states('retinaface'), **kw),
+           Recognition(device=0, state=states('arcface'), **kw),
+           Estimation(short_side=96, device=0, state=states('openpose_decoder'), **kw))
+    two = (Detection(short_side=128, device=[0, 0], state=states('retinaface'), **kw),
+           Recognition(device=[0, 0], state=states('arcface'), **kw),
+           Estimation(short_side=96, device=[0, 0], state=states('openpose_decoder'), **kw))
+    assert len(two[0]._fanout.replicas) == 2
+    assert two[0]._fanout.replicas[0].model.ctx is not two[0]._fanout.replicas[1].model.ctx
+
+    def run(fx, frames, pframes):
+        det, rec, est = fx
+        dets = det(frames)
+        faces = [d[:2] for d in dets]
+        faces[0] = []                                                # an image without faces inside a shard
+        return dets, rec(list(frames), faces), est(pframes)
+
+    def same(a, b):
+        assert len(a[0]) == len(b[0]) and [len(x) for x in a[0]] == [len(x) for x in b[0]]
+        for x, y in zip(a[0], b[0]):
+            for p, q in zip(x, y):
+                assert all(np.array_equal(p[k], q[k]) for k in ('bbox', 'landmarks', 'score'))
+        assert len(a[1]) == len(b[1])
+        for x, y in zip(a[1], b[1]):
+            assert x.dtype == y.dtype and np.array_equal(x, y)
+        assert [len(x) for x in a[2]] == [len(x) for x in b[2]]
+        for x, y in zip(a[2], b[2]):
+            for p, q in zip(x, y):
+                assert np.array_equal(p['keypoints'], q['keypoints']) and p['score'] == q['score']
+    frames = synth.frames(0, 5, 240, 320)                           # 5 frames over 2 devices: 3 + 2
+    pframes = synth.pose_code_frames(60, 5, 96, 128, 3)
+    a, b = run(one, frames, pframes), run(two, frames, pframes)
+    same(a, b)
+    assert sum(len(d) for d in a[0]) > 0 and sum(len(p) for p in a[2]) >= 10
+    lst = [frames[0], frames[1][:200, :260], frames[2][:180]]        # different sizes: one canvas for the whole list
+    plst = [pframes[0], pframes[1][9:88, 14:115], pframes[2]]
+    same(run(one, lst, plst), run(two, lst, plst))
+    same(run(one, frames[:1], pframes[:1]), run(two, frames[:1], pframes[:1]))        # fewer frames than devices
+    single = two[0](frames[0])
+    assert isinstance(single, list) and (not single or isinstance(single[0], dict))
+    with pytest.raises(NotImplementedError):
+        Detection(merge_method='crop', device=[0, 0], state=states('retinaface'))(lst)

@@ -215,3 +215,34 @@ def test_pack_cache_roundtrip(tmp_path, states, monkeypatch):
     assert pack.pack_arcface(sa, 'f32').blob() != pack.pack_arcface(sa, 'bf16x3').blob()
     with pytest.raises(ValueError):
         runtime.resolve_state('openpose', None)                   # no file, no synthetic fallback
+
+
+def test_fanout_shards_contiguously_and_keeps_order(monkeypatch):
+    """facade._Fanout (single-process multi-device) with stand-in replicas: contiguous shards in device
+    order, sizes differing by at most one, aligned per-item arguments sharded alike, keyword arguments passed on,
+    devices beyond the batch size left idle, first replica of a device on the shared context and repeats on new ones."""
+    from terran_amd import facade, runtime
+    made = []
+    monkeypatch.setattr(runtime, 'get_context', lambda d=None: ('shared', d))
+    monkeypatch.setattr(runtime, 'new_context', lambda d=None: ('new', d))
+    calls = []
+
+    def make(dev, ctx):
+        made.append((dev, ctx))
+
+        def rep(items, *per, **kw):
+            calls.append((dev, ctx, list(items), [list(p) for p in per], kw))
+            return [(x, ctx) for x in items]
+        return rep
+    fo = facade._Fanout([0, 1, 0], make)
+    assert made == [(0, ('shared', 0)), (1, ('shared', 1)), (0, ('new', 0))]
+    out = fo(list(range(8)), list('abcdefgh'), _canvas=(3, 4))
+    assert [x for x, _ in out] == list(range(8))                                       # frame order kept
+    got = sorted(calls, key=lambda c: c[2][0])
+    assert [c[2] for c in got] == [[0, 1, 2], [3, 4, 5], [6, 7]]                       # contiguous, sizes differ by <= 1
+    assert [c[3] for c in got] == [[list('abc')], [list('def')], [list('gh')]]
+    assert all(c[4] == {'_canvas': (3, 4)} for c in got)
+    calls.clear()
+    assert [x for x, _ in fo(np.arange(2))] == [0, 1] and len(calls) == 2              # third device idle
+    with pytest.raises(ValueError):
+        facade._Fanout([], make)
