@@ -9,19 +9,34 @@ a batch of B=32 synthetic 1080p RGB frames per GPU per step, ALREADY RESIDENT in
   Detection(short_side=416)  -> RetinaFace 416x739 + decode/NMS          (face/detection/__init__.py)
   Recognition(top-F faces)   -> similarity warp + ArcFace-R100 + L2 norm   (face/recognition/__init__.py)
   Estimation(short_side=184) -> OpenPose 184x327 + x8 bicubic + grouping   (pose/__init__.py)
-with random-init weights of the exact architectures (no checkpoints offline) and the full host
-side of the wrappers (result download, dict construction, landmark alignment math).
+with random-init weights of the exact architectures (no checkpoints offline) and the full host side of the wrappers
+(result download, dict construction, landmark alignment math).  The frames carry pose maps and the pose weights hold the
+matching decoder path (terran_amd/weights.py:make_openpose_decoder_state), so people DO assemble (4 per frame).
 One "step" = one such batch (F = 2 faces per frame by default; F = 1 and F = 4, the counts SURVEY.md 8d quotes, are
 measured as well and reported under `other_faces_per_frame`).  Per GPU the host keeps two batches in flight, each on
 three threads / HIP streams (detect -> queue -> embed, pose); all K steps complete inside the timed region.  Frames
 shard embarrassingly: every rank owns its own batches, there is no data-path collective ("scaling": "weak").
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for `roofline` and `cpu_baseline`).
+The ONE JSON line rank 0 prints carries, next to the headline (`value`: bf16x3 mode, frames resident in HBM):
+  value_f32 / roofline_f32      the same workload with every conv on the exact-f32 MFMA (the like-for-like arithmetic)
+  sustained                     the headline mode again over a >= 2 s timed region (the driver's K may be short)
+  ingest                        the same workload fed from HOST memory: a raw rgb24 byte stream read into pinned buffers
+                                and uploaded by video.RawVideoReader threads (upload overlapped with compute), results
+                                gathered in order on rank 0 every step -- the SURVEY.md 8(e) pipeline with its scatter
+                                (H2D) and gather inside the timed region
+  per_model                     BASELINE configs C2 (RetinaFace 32x640x640), C3 (ArcFace 256 crops), C4 (OpenPose
+                                16x368x656), each with its own roofline (N = 1 only)
+  roofline / cpu_baseline       see README / DESIGN.md section 5
+`python bench.py --gpus N --single-process` (no torchrun) drives N devices from ONE process through the facades'
+device-list fan-out (facade._Fanout) instead of one process per GPU.
 """
 import argparse
+import io
 import json
 import os
+import queue
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,37 +46,101 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 H, W = 1080, 1920
-# Dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md (spec): f32-input 157.3 TFLOP/s, bf16 2.5 PFLOP/s.
+# Dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md (spec): f32-input 157.3 TFLOP/s, bf16 2.5 PFLOP/s; HBM 8 TB/s.
 # precision -> (peak of the MFMA opcode used, note, MFMA flops issued per algorithmic flop)
 PEAKS = {
     'f32': (157.3, 'v_mfma_f32_32x32x2_f32 (exact f32)', 1),
     'bf16x3': (2500.0, 'v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi, f32 accumulate)', 3),
     'bf16': (2500.0, 'v_mfma_f32_32x32x16_bf16', 1),
 }
+HBM_PEAK_GBPS = 8000.0
 DTYPES = {'f32': 'f32',
-          'bf16x3': 'bf16x3 (operands x = hi + lo as two bf16, ~16 mantissa bits; 3 bf16 MFMAs per product term, f32 '
-                    'accumulate; RetinaFace activations stay f32) -- passes the same 1e-3 / bit-exact parity suite as f32',
+          'bf16x3': 'bf16x3 (ArcFace / OpenPose operands x = hi + lo as two bf16, ~16 mantissa bits; 3 bf16 MFMAs per '
+                    'product term, f32 accumulate; the detector RetinaFace runs on the exact-f32 MFMA) -- passes the '
+                    'same 1e-3 / bit-exact parity suite as f32',
           'bf16': 'bf16 (f32 accumulate)'}
+KLASSES = ('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')
+
+
+def conv_roofline(precision, conv):
+    """`conv` = {'ms','launches','work'} of the implicit-GEMM kernels from HIP events on their launch streams."""
+    achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+    peak, note, factor = PEAKS[precision]
+    r = {
+        'kernel': 'conv_igemm_split / conv_igemm_pipe / conv_igemm, %s' % note,
+        'bound': 'mfma',
+        'achieved': round(achieved, 2),
+        'peak': peak,
+        'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4),
+        'traffic': None,
+        'launches_per_step': conv['launches'],
+        'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
+        'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
+        'mfma_flops_per_algorithmic_flop': factor,
+        'mfma_issue_frac': round(achieved * factor / peak, 4),
+        'source': 'driver-run: HIP events around every conv launch of one serial step of this very process',
+    }
+    # The fields below are NOT measured by this run: they replay the builder's rocprofv3 --pmc passes of the same
+    # command (profiles/README.md), committed as JSON.
+    pmc = os.path.join(REPO, 'profiles', 'pmc_conv_%s.json' % precision)
+    if os.path.exists(pmc):
+        r['traffic'] = round(json.load(open(pmc))['hbm_bytes_per_launch'])
+        r['traffic_source'] = ('builder-run: profiles/pmc_conv_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes '
+                               'per conv launch)' % precision)
+    pm = os.path.join(REPO, 'profiles', 'pmc_mfma.json')
+    if os.path.exists(pm):
+        c = json.load(open(pm)).get(precision)
+        if c:
+            r['pmc_dominant_layers'] = dict(c, source='builder-run: profiles/pmc_mfma.json (tools/clock_probe.sh)')
+    return r
+
+
+class LoopStream(io.RawIOBase):
+    """`n_batches` copies of one frame batch as a raw rgb24 byte stream (what `ffmpeg -f rawvideo -pix_fmt rgb24 pipe:`
+    delivers, terran/io/video/reader.py:421-465): readinto() is one host memcpy out of the batch, like a pipe read."""
+
+    def __init__(self, batch, n_batches):
+        self.buf = memoryview(np.ascontiguousarray(batch).reshape(-1))
+        self.left = len(self.buf) * n_batches
+        self.pos = 0
+
+    def readable(self):
+        return True
+
+    def readinto(self, b):
+        n = min(len(b), self.left, len(self.buf) - self.pos)
+        if n <= 0:
+            return 0
+        b[:n] = self.buf[self.pos:self.pos + n]
+        self.pos = (self.pos + n) % len(self.buf)
+        self.left -= n
+        return n
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=120)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
     ap.add_argument('--cpu-frames', type=int, default=16, help='frames in the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or bf16x3)')
-    ap.add_argument('--single-mode', action='store_true', help='skip the secondary f32-MFMA measurement')
+    ap.add_argument('--single-mode', action='store_true',
+                    help='headline measurement only (no f32 / faces-per-frame / sustained / ingest / per-model legs)')
     ap.add_argument('--inflight', type=int, default=2, help='batches in flight per GPU (pipelines of 3 streams each)')
     ap.add_argument('--serial', action='store_true',
                     help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
                          'rocprofv3 kernel statistics under profiles/ are taken in, so that their per-kernel averages '
                          'are comparable with the HIP-event roofline figures')
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
+    ap.add_argument('--sustain-seconds', type=float, default=2.5, help='length of the `sustained` timed region')
+    ap.add_argument('--single-process', action='store_true',
+                    help='--gpus N devices driven by ONE process through the facades\' device-list fan-out')
+    ap.add_argument('--devices', default=None, help='with --single-process: comma-separated device ids (repeats allowed)')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): everything libraries print to fd 1 (RCCL's version banner, for
@@ -69,17 +148,37 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    try:
+        result = run_single_process(args) if args.single_process else run(args)
+    finally:
+        sys.stdout.flush()
+    if result is not None:
+        os.write(real_stdout, (json.dumps(result) + '\n').encode())
+    os.close(real_stdout)
 
+
+def make_workload(args, rank):
+    from terran_amd import synth, weights
+    sd = (weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_decoder_state())
+    # C5 seed 4.  1080p frames whose bilinear 184 x 327 reduction is a frame that carries 4 people
+    frames_host = synth.upscale_for_resize(synth.pose_code_frames(4 + rank, args.batch, 184, 327, 4), H, W)
+    fallback_lm = synth.landmarks(77, max(4, args.faces), H, W)
+    return sd, frames_host, fallback_lm
+
+
+def run(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+            sys.exit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d (or add --single-process)'
+                     % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
     dist = None
+    gather_group = None
     # RCCL (backend "nccl") on the GPU box; TA_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a
     # single-GPU box (ranks then share device LOCAL_RANK % device_count).
     backend = os.environ.get('TA_BENCH_BACKEND', 'nccl')
@@ -92,10 +191,11 @@ def main():
             torch.cuda.set_device(device_index)
             dist.init_process_group(backend='nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', device_index))
+            gather_group = dist.new_group(backend='gloo')            # host-side ordered gather of result objects
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    from terran_amd import Detection, Recognition, Estimation, runtime, synth, weights
+    from terran_amd import Detection, Recognition, Estimation, runtime, shard, video
 
     # Host side: a pipeline of three host threads per GPU, each with its own context (HIP stream + scratch):
     # detection, embedding (fed the detections of its batch through a queue) and pose.  Kernels of the streams
@@ -105,18 +205,15 @@ def main():
     # buffers are parked per context instead of hipFree'd (hipFree waits for every stream of the process).
     # `--inflight L` runs L such pipelines on alternate batches (default 2 batches in flight: with one workgroup per
     # CU per conv kernel the extra streams fill more gaps: 1890 -> 1945 frames/s; L = 3 adds nothing).
-    import queue
     from concurrent.futures import ThreadPoolExecutor
     # a thread coming back from a (GIL-free) library call must not wait a whole 5 ms interpreter time slice behind
     # another thread's result handling before it can queue its next launch
     sys.setswitchinterval(float(os.environ.get('TA_BENCH_SWITCH', '2e-4')))
-    sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_state()
-    frames_host = synth.frames(4 + rank, args.batch, H, W)        # C5 seed 4
+    (sd_r, sd_a, sd_p), frames_host, fallback_lm = make_workload(args, rank)
     F = args.faces
     face_state = {'F': F}                                               # pick_faces reads the current faces-per-frame
-    fallback_lm = synth.landmarks(77, 4 if F < 4 else F, H, W)
     L = max(1, args.inflight)
-    pool = ThreadPoolExecutor(max_workers=3 * L)
+    pool = ThreadPoolExecutor(max_workers=5 * L + 2)    # per pipeline: detect, embed, pose (+ feeder, collector when streaming)
 
     def pick_faces(dets):
         faces, nf = [], face_state['F']
@@ -150,28 +247,73 @@ def main():
             dets = self.det(self.frames[0])
             return dets, self.rec.model.call(self.frames[1], pick_faces(dets)), self.est(self.frames[2])
 
-        def start(self, k):
-            """Queue k steps on this pipeline's three threads; returns a callable that joins them."""
+        def start(self, k, reader=None, on_step=None):
+            """Queue k steps on this pipeline's three threads; returns a callable that joins them.
+            reader: a video.RawVideoReader -- every step then takes its OWN batch from it (host -> HBM inside the timed
+            region) instead of the resident one, and frees it once all three tasks are through with it.
+            on_step(dets, feats, poses): called per finished step (ordered gather)."""
             if k == 0:
                 return lambda: None
             q = queue.Queue()
+            src = [queue.Queue() for _ in range(3)]
+            done = queue.Queue()
+
+            def feeder():                                   # hands batch i to the three task threads
+                for _ in range(k):
+                    batch = next(reader)
+                    for s in src:
+                        s.put(batch)
 
             def detect_loop():
                 res = []
                 for _ in range(k):
-                    res.append(self.det(self.frames[0]))
+                    fr = src[0].get() if reader else self.frames[0]
+                    res.append(self.det(fr))
                     q.put(res[-1])
+                    if reader:
+                        done.put(('det', (fr, res[-1])))
                 return res
 
             def embed_loop():
-                return [self.rec.model.call(self.frames[1], pick_faces(q.get())) for _ in range(k)]
+                res = []
+                for _ in range(k):
+                    fr = src[1].get() if reader else self.frames[1]
+                    res.append(self.rec.model.call(fr, pick_faces(q.get())))
+                    if reader:
+                        done.put(('rec', res[-1]))
+                return res
 
             def pose_loop():
-                return [self.est(self.frames[2]) for _ in range(k)]
+                res = []
+                for _ in range(k):
+                    fr = src[2].get() if reader else self.frames[2]
+                    res.append(self.est(fr))
+                    if reader:
+                        done.put(('est', res[-1]))
+                return res
             futs = [pool.submit(f) for f in (detect_loop, embed_loop, pose_loop)]
+            if reader:
+                pool.submit(feeder)
+
+                def collect():
+                    # the three tasks of one batch finish in any order relative to OTHER batches' tasks, but each task
+                    # thread walks the batches in order: the i-th message of every kind belongs to batch i
+                    kinds = {'det': [], 'rec': [], 'est': []}
+                    emitted = 0
+                    for _ in range(3 * k):
+                        name, val = done.get()
+                        kinds[name].append(val)
+                        while emitted < min(len(v) for v in kinds.values()):
+                            fr, dets = kinds['det'][emitted]
+                            fr.free()
+                            if on_step:
+                                on_step(dets, kinds['rec'][emitted], kinds['est'][emitted])
+                            emitted += 1
+                futs.append(pool.submit(collect))
 
             def join():
-                d, e, p_ = [f.result() for f in futs]
+                outs = [f.result() for f in futs]
+                d, e, p_ = outs[:3]
                 assert len(d) == k and len(e) == k and len(p_) == k       # every step produced all three results
                 return d[-1], e[-1], p_[-1]
             return join
@@ -194,7 +336,7 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
-    def run_steps(k):
+    def run_steps(k, readers=None, on_step=None):
         """k steps, pipeline p taking steps p, p+L, ...; with --join-steps one step at a time on pipeline 0."""
         if args.serial:
             for _ in range(k):
@@ -204,33 +346,31 @@ def main():
             for _ in range(k):
                 res = pipes[0].start(1)()
             return res
-        joins = [p.start(len(range(i, k, L))) for i, p in enumerate(pipes)]
+        joins = [p.start(len(range(i, k, L)), readers[i] if readers else None, on_step) for i, p in enumerate(pipes)]
         outs = [j() for j in joins]
         return next(o for o in outs if o is not None)
 
-    def run_mode(precision):
-        """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then one serial
-        step with a HIP event pair around every launch for the per-kernel roofline."""
-        for p in pipes:
-            p.load(precision)
-        if args.warmup:
-            run_steps(max(args.warmup, L))                          # every pipeline warms its plans
+    def timed(k, **kw):
         sync()
         t0 = time.perf_counter()
-        out = run_steps(args.steps)
+        out = run_steps(k, **kw)
         sync()
         elapsed = time.perf_counter() - t0
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        return elapsed, out
+
+    def profile_serial_step():
+        """One serial step with a HIP event pair around every launch (per-kernel-class time and algorithmic work)."""
         p0 = pipes[0]
         for c in p0.ctxs:
             c.profile_reset()
             c.profile(True)
         p0.serial_step()
         klass = {}
-        for k, name in enumerate(('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')):
+        for k, name in enumerate(KLASSES):
             ms = n = work = 0
             for c in p0.ctxs:
                 a, b, w_ = c.profile_read(k)
@@ -238,48 +378,115 @@ def main():
             klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
         for c in p0.ctxs:
             c.profile(False)
+        return klass
+
+    def run_mode(precision, steps, extra=None):
+        """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then the profiled serial step.
+        extra(result_dict): further legs measured while this mode's models are loaded."""
+        for p in pipes:
+            p.load(precision)
+        if args.warmup:
+            run_steps(max(args.warmup, L))                          # every pipeline warms its plans
+        elapsed, out = timed(steps)
+        res = {'elapsed': elapsed, 'out': out, 'klass': profile_serial_step()}
+        if extra:
+            extra(res)
         for p in pipes:
             p.unload()
-        return elapsed, out, klass
+        return res
 
-    def roofline(precision, klass):
-        conv = klass['conv_igemm']
-        achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
-        peak, note, factor = PEAKS[precision]
-        r = {
-            'kernel': 'conv_igemm / conv_igemm_pipe, %s' % note,
-            'bound': 'mfma',
-            'achieved': round(achieved, 2),
-            'peak': peak,
-            'unit': 'TFLOP/s',
-            'frac': round(achieved / peak, 4),
-            'traffic': None,
-            'launches_per_step': conv['launches'],
-            'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
-            'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
-            'mfma_flops_per_algorithmic_flop': factor,
-            'mfma_issue_frac': round(achieved * factor / peak, 4),
-        }
-        pmc = os.path.join(REPO, 'profiles', 'pmc_conv_%s.json' % precision)
-        if os.path.exists(pmc):                       # rocprofv3 --pmc passes of this same command (profiles/README.md)
-            r['traffic'] = round(json.load(open(pmc))['hbm_bytes_per_launch'])
-            r['traffic_source'] = 'profiles/pmc_conv_%s.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % precision
-        pm = os.path.join(REPO, 'profiles', 'pmc_mfma.json')
-        if os.path.exists(pm):                        # hardware counters on the dominant layers (profiles/README.md)
-            c = json.load(open(pm)).get(precision)
-            if c:
-                r['pmc_dominant_layers'] = dict(c, source='profiles/pmc_mfma.json (tools/clock_probe.sh)')
-        return r
+    def fps(elapsed, steps):
+        return round(args.batch * steps * world / elapsed, 3)
+
+    def extra_headline(res):
+        if args.single_mode or args.serial or args.join_steps:
+            return
+        # -- sustained: the same measurement over a region of >= --sustain-seconds
+        per_step = res['elapsed'] / args.steps
+        k = max(args.steps, int(np.ceil(args.sustain_seconds / per_step)))
+        e, _ = timed(k)
+        res['sustained'] = {'steps': k, 'seconds': round(e, 3), 'value': fps(e, k), 'ms_per_step': round(e / k * 1e3, 3)}
+        # -- ingest: frames come from host memory through RawVideoReader (pinned double buffers, own upload stream per
+        #    pipeline), results are gathered in step order on rank 0 inside the timed region
+        k = max(2 * L, min(args.steps, 60))
+        gathered = []
+        lock = threading.Lock()
+
+        def on_step(dets, feats, poses):
+            item = (dets, feats, poses)
+            if use_dist:
+                item = shard.gather_results([item], dist if gather_group is None else _GroupDist(dist, gather_group))
+            with lock:
+                if item is not None:
+                    gathered.append(item)
+        # gather_object is a collective: with more than one rank the steps must be gathered in the same order
+        # everywhere, so under torchrun each rank gathers from ONE collector thread (pipeline order = step order)
+        readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, L))), W, H,
+                                        batch_size=args.batch, device=device_index) for i in range(L)]
+        try:
+            run_steps(2 * L, readers=readers)                                        # warm the readers' buffers
+            if use_dist and world > 1:
+                e, _ = timed_ingest_ordered(k, readers, on_step)
+            else:
+                e, _ = timed(k, readers=readers, on_step=on_step)
+        finally:
+            for r in readers:
+                r.close()
+        res['ingest'] = {
+            'value': fps(e, k), 'unit': 'frames/s', 'steps': k, 'ms_per_step': round(e / k * 1e3, 3),
+            'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
+            'steps_gathered_on_rank0': len(gathered),
+            'what': 'same workload, every batch read from a raw rgb24 byte stream in host memory into pinned buffers and '
+                    'uploaded by video.RawVideoReader (one reader thread + upload stream per pipeline, overlapped with '
+                    'compute), per-step results gathered in order on rank 0; stream reads are single-thread host memcpys '
+                    '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
+
+    def timed_ingest_ordered(k, readers, on_step):
+        """Multi-rank ingest: steps run as in run_steps but results are handed to the collective gather strictly in
+        step order by one thread (pipelines finish out of order relative to each other)."""
+        slots = {}
+        cv = threading.Condition()
+
+        def make_cb(pi):
+            count = [0]
+
+            def cb(dets, feats, poses):
+                with cv:
+                    slots[pi + L * count[0]] = (dets, feats, poses)
+                    count[0] += 1
+                    cv.notify_all()
+            return cb
+
+        def gatherer():
+            for s in range(k):
+                with cv:
+                    cv.wait_for(lambda: s in slots)
+                    item = slots.pop(s)
+                on_step(*item)
+        sync()
+        t0 = time.perf_counter()
+        g = pool.submit(gatherer)
+        joins = [p.start(len(range(i, k, L)), readers[i], make_cb(i)) for i, p in enumerate(pipes)]
+        outs = [j() for j in joins]
+        g.result()
+        sync()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), outs
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'bf16x3')
-    elapsed, out, klass = run_mode(primary)
+    head = run_mode(primary, args.steps, extra_headline)
+    elapsed, out, klass = head['elapsed'], head['out'], head['klass']
     others = {}
     if not args.single_mode:
         for prec in ('f32',):
             if prec != primary:
-                e2, _, k2 = run_mode(prec)
-                others[prec] = {'value': round(args.batch * args.steps * world / e2, 3),
-                                'ms_per_step': round(e2 / args.steps * 1e3, 3), 'roofline': roofline(prec, k2)}
+                steps2 = max(L, args.steps // 2)
+                r2 = run_mode(prec, steps2)
+                others[prec] = {'value': fps(r2['elapsed'], steps2), 'steps': steps2,
+                                'ms_per_step': round(r2['elapsed'] / steps2 * 1e3, 3),
+                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm'])}
 
     # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
     other_faces = {}
@@ -287,24 +494,25 @@ def main():
         for nf in (1, 4):
             if nf != F:
                 face_state['F'] = nf
-                e3, _, k3 = run_mode(primary)
-                other_faces[str(nf)] = {'value': round(args.batch * args.steps * world / e3, 3),
-                                        'ms_per_step': round(e3 / args.steps * 1e3, 3),
-                                        'algorithmic_gflop_per_step': round(k3['conv_igemm']['work'] / 1e9, 1)}
+                steps3 = max(L, args.steps // 2)
+                r3 = run_mode(primary, steps3)
+                other_faces[str(nf)] = {'value': fps(r3['elapsed'], steps3), 'steps': steps3,
+                                        'ms_per_step': round(r3['elapsed'] / steps3 * 1e3, 3),
+                                        'algorithmic_gflop_per_step': round(r3['klass']['conv_igemm']['work'] / 1e9, 1)}
         face_state['F'] = F
 
     result = None
     if rank == 0:
         dets, feats, poses = out
-        total_frames = args.batch * args.steps * world
         result = {
             'metric': 'frames/sec 1080p detect+embed+pose',
-            'value': round(total_frames / elapsed, 3),
+            'value': fps(elapsed, args.steps),
             'unit': 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'timed_region_s': round(elapsed, 3),
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -313,14 +521,14 @@ def main():
             'config': {
                 'workload': 'BASELINE configs[4]: 1080p frames, %d per GPU per step, resident in HBM; '
                             'Detection(short_side=416) + Recognition(top-%d faces/frame) + '
-                            'Estimation(short_side=184); random-init weights (seeds 100/101/102)'
+                            'Estimation(short_side=184); random-init weights (seeds 100/101/102; the pose weights '
+                            'carry the decoder path that turns the frames\' embedded pose maps into 4 people per frame)'
                             % (args.batch, F),
                 'precision': primary,
                 'frames_per_gpu_step': args.batch,
                 'faces_per_frame': F,
                 'detections_per_frame': round(float(np.mean([len(d) for d in dets])), 1),
                 'humans_per_frame': round(float(np.mean([len(p) for p in poses])), 2),
-                # the random-weight pose net rarely assembles a person but keeps the grouping stage busy:
                 'pose_peaks_per_frame': round(pipes[0].ctxs[2].pose_stats()[0] / float(args.batch), 1),
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
@@ -332,27 +540,161 @@ def main():
                                 '... (embed consumes the detections of its batch through a queue); joined once at '
                                 'the end of the timed region' % (L, L),
             },
-            'roofline': roofline(primary, klass),
+            'roofline': conv_roofline(primary, klass['conv_igemm']),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
             # algorithmic bytes / kernel time of the HBM-bound kernel classes (peak 8000 GB/s); post-processing
-            # mixes the 430 MB x8-upsample stream with latency-bound selection / grouping kernels
+            # mixes the pose-map stream with latency-bound selection / grouping kernels
             'stage_hbm_gbps': {k: round(v['work'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in klass.items()
                                if k != 'conv_igemm' and v['ms'] > 0},
-            'other_precisions': others,
-            'other_faces_per_frame': other_faces,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
+        if 'f32' in others:                                          # the like-for-like reference arithmetic, top level
+            result['value_f32'] = others['f32']['value']
+            result['ms_per_step_f32'] = others['f32']['ms_per_step']
+            result['roofline_f32'] = others['f32']['roofline']
+        for key in ('sustained', 'ingest'):
+            if key in head:
+                result[key] = head[key]
+        result['other_precisions'] = others
+        result['other_faces_per_frame'] = other_faces
     for p in pipes:
         p.free()
     pool.shutdown()
+    if rank == 0 and world == 1 and not args.single_mode:
+        result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(result) + '\n').encode())
-    os.close(real_stdout)
+    return result
+
+
+class _GroupDist:
+    """`shard.gather_results` over a specific process group (the host-side gloo group next to RCCL)."""
+
+    def __init__(self, dist, group):
+        self._dist, self._group = dist, group
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self):
+        return self._dist.get_world_size()
+
+    def get_rank(self):
+        return self._dist.get_rank()
+
+    def gather_object(self, obj, bucket, dst=0):
+        return self._dist.gather_object(obj, bucket, dst=dst, group=self._group)
+
+
+# ---- BASELINE configs C2 / C3 / C4 on one GPU (tools/model_bench.py prints the same rows) -------------------------
+# Algorithmic work per unit, SURVEY.md 8(d) / BASELINE.md section 3 (conv + linear, FLOP = 2 MAC; bytes = layer-wise
+# unfused activation traffic at 2 B/element + weights once per batch).
+C2_BYTES_PER_IMAGE, C2_WEIGHT_BYTES = 56.3e6, 0.84e6
+C3_GFLOP_PER_CROP, C4_GFLOP_PER_IMAGE, C2_GFLOP_PER_IMAGE = 24.1792, 484.634, 1.9623
+
+
+def per_model(ctx, precisions, reps=8):
+    from terran_amd import arcface, openpose, retinaface, synth, weights
+
+    def timed(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        ctx.profile_reset()
+        ctx.profile(True)
+        fn()
+        ctx.sync()
+        prof = {name: ctx.profile_read(k) for k, name in enumerate(KLASSES)}
+        ctx.profile(False)
+        return dt, prof
+    sd_r, sd_a, sd_p = weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_decoder_state()
+    c2 = ctx.upload(synth.frames(1, 32, 640, 640))                                   # SURVEY.md 8(d) seeds 1 / 2 / 3
+    c3 = np.random.default_rng(2).integers(0, 256, (256, 3, 112, 112), dtype=np.uint8)
+    c4 = ctx.upload(synth.pose_code_frames(3, 16, 368, 656, 6))
+    rows = {}
+    for prec in precisions:
+        det = retinaface.RetinaFace(device=ctx.device_id, state=sd_r, precision=prec, ctx=ctx)
+        dt, prof = timed(lambda: det.call_frames(c2), reps)
+        dev_ms = sum(p[0] for p in prof.values())
+        bytes_batch = 32 * C2_BYTES_PER_IMAGE + C2_WEIGHT_BYTES
+        rows['C2 RetinaFace 32x640x640 ' + prec] = {
+            'images_per_s': round(32 / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'device_kernel_ms': round(dev_ms, 3),
+            'host_share': round(max(0.0, 1.0 - dev_ms * 1e-3 / dt), 3), 'kernel_launches': int(sum(p[1] for p in prof.values())),
+            'conv_tflops': round(prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9, 1),
+            'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+                         'achieved': round(bytes_batch / (dev_ms * 1e-3) / 1e9, 1),
+                         'frac': round(bytes_batch / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         'achieved_wall': round(bytes_batch / dt / 1e9, 1),
+                         'algorithmic_bytes_per_image': C2_BYTES_PER_IMAGE,
+                         'note': 'SURVEY.md 8(d) unfused bf16 activation bytes (56.3 MB/img + 0.84 MB weights per batch) / '
+                                 'summed kernel time of the whole call (achieved) and / wall time per batch (achieved_wall)'}}
+        det.model.free()
+        arc = arcface.ArcFace(device=ctx.device_id, state=sd_a, precision=prec, ctx=ctx)
+        dt, prof = timed(lambda: arc.embed_crops(c3), max(2, reps // 2))
+        tf = prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9
+        peak, _, factor = PEAKS[prec]
+        rows['C3 ArcFace 256x3x112x112 ' + prec] = {
+            'images_per_s': round(256 / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'conv_ms': round(prof['conv_igemm'][0], 3),
+            'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'achieved': round(tf, 1), 'frac': round(tf / peak, 4),
+                         'mfma_issue_frac': round(tf * factor / peak, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP}}
+        arc.model.free()
+        pose = openpose.OpenPose(device=ctx.device_id, short_side=368, state=sd_p, precision=prec, ctx=ctx)
+        res = []
+        dt, prof = timed(lambda: res.append(pose.call_frames(c4)), max(2, reps // 2))
+        tf = prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9
+        rows['C4 OpenPose 16x368x656 ' + prec] = {
+            'images_per_s': round(16 / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'conv_ms': round(prof['conv_igemm'][0], 3),
+            'grouping_ms': round(prof['postprocess'][0], 3), 'humans_per_frame': round(sum(len(p) for p in res[-1]) / 16.0, 2),
+            'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'achieved': round(tf, 1), 'frac': round(tf / peak, 4),
+                         'mfma_issue_frac': round(tf * factor / peak, 4), 'algorithmic_gflop_per_image': C4_GFLOP_PER_IMAGE}}
+        pose.model.free()
+    c2.free()
+    c4.free()
+    return rows
+
+
+def run_single_process(args):
+    """--single-process: ONE process, one host thread + context + weights per device (facade device lists), host
+    frames scattered as contiguous sub-batches and results gathered in order (SURVEY.md 8e as specified)."""
+    from terran_amd import Detection, Recognition, Estimation, lib, runtime
+    devices = [int(d) for d in args.devices.split(',')] if args.devices else list(range(args.gpus))
+    n = len(devices)
+    (sd_r, sd_a, sd_p), one, fallback_lm = make_workload(args, 0)
+    frames_host = np.concatenate([one] * n) if n > 1 else one          # B frames per device per step
+    prec = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'bf16x3')
+    det = Detection(short_side=416, device=devices, state=sd_r, precision=prec)
+    rec = Recognition(device=devices, state=sd_a, precision=prec)
+    est = Estimation(short_side=184, device=devices, state=sd_p, precision=prec)
+    F = args.faces
+
+    def step():
+        dets = det(frames_host)
+        faces = [[{'landmarks': x['landmarks']} for x in d[:F]] +
+                 [{'landmarks': fallback_lm[k]} for k in range(len(d[:F]), F)] for d in dets]
+        return dets, rec(list(frames_host), faces), est(frames_host)
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    elapsed = time.perf_counter() - t0
+    return {
+        'metric': 'frames/sec 1080p detect+embed+pose', 'value': round(len(frames_host) * args.steps / elapsed, 3),
+        'unit': 'frames/s', 'n_gpus': len(set(devices)), 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': DTYPES[prec], 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[4], single process: %d device replicas %s, %d host frames per replica per '
+                               'step scattered from one host array (PCIe upload inside the timed region), detect -> embed -> '
+                               'pose back to back, ordered gather' % (n, devices, args.batch),
+                   'precision': prec, 'frames_per_step': len(frames_host), 'faces_per_frame': F,
+                   'humans_per_frame': round(float(np.mean([len(p) for p in out[2]])), 2)}}
 
 
 def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
