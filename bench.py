@@ -257,6 +257,7 @@ def run(args):
             q = queue.Queue()
             src = [queue.Queue() for _ in range(3)]
             done = queue.Queue()
+            WAIT = 300.0                                     # a task thread that died must not block the others forever
 
             def feeder():                                   # hands batch i to the three task threads
                 for _ in range(k):
@@ -267,7 +268,7 @@ def run(args):
             def detect_loop():
                 res = []
                 for _ in range(k):
-                    fr = src[0].get() if reader else self.frames[0]
+                    fr = src[0].get(timeout=WAIT) if reader else self.frames[0]
                     res.append(self.det(fr))
                     q.put(res[-1])
                     if reader:
@@ -277,8 +278,8 @@ def run(args):
             def embed_loop():
                 res = []
                 for _ in range(k):
-                    fr = src[1].get() if reader else self.frames[1]
-                    res.append(self.rec.model.call(fr, pick_faces(q.get())))
+                    fr = src[1].get(timeout=WAIT) if reader else self.frames[1]
+                    res.append(self.rec.model.call(fr, pick_faces(q.get(timeout=WAIT))))
                     if reader:
                         done.put(('rec', res[-1]))
                 return res
@@ -286,7 +287,7 @@ def run(args):
             def pose_loop():
                 res = []
                 for _ in range(k):
-                    fr = src[2].get() if reader else self.frames[2]
+                    fr = src[2].get(timeout=WAIT) if reader else self.frames[2]
                     res.append(self.est(fr))
                     if reader:
                         done.put(('est', res[-1]))
@@ -301,7 +302,7 @@ def run(args):
                     kinds = {'det': [], 'rec': [], 'est': []}
                     emitted = 0
                     for _ in range(3 * k):
-                        name, val = done.get()
+                        name, val = done.get(timeout=WAIT)
                         kinds[name].append(val)
                         while emitted < min(len(v) for v in kinds.values()):
                             fr, dets = kinds['det'][emitted]
@@ -312,7 +313,7 @@ def run(args):
                 futs.append(pool.submit(collect))
 
             def join():
-                outs = [f.result() for f in futs]
+                outs = [f.result(timeout=2 * WAIT) for f in futs]
                 d, e, p_ = outs[:3]
                 assert len(d) == k and len(e) == k and len(p_) == k       # every step produced all three results
                 return d[-1], e[-1], p_[-1]

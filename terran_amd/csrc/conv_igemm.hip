@@ -627,6 +627,145 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Depthwise 3x3 (+BN+ReLU) fused into the following 1x1 conv (+BN+ReLU): RetinaFace's ConvSepBlock chain
+// (retinaface/model.py:26-39, 60-99) regrouped as [dw_k -> pw_{k+1}].  The graph is HBM-bound (35 FLOP/B): the
+// depthwise output never leaves the CU.  Same tile machinery as conv_igemm above (weights DMA'd per K slab, fragments,
+// epilogue), but the pixel rows of a slab are COMPUTED into LDS -- 9 taps x 16-byte loads per (pixel, 4 channels), fmaf
+// chain in (ky, kx) order exactly like dwconv3x3_kernel -- instead of DMA'd.  Exact-f32 MFMA only (the detector runs
+// on it in both parity modes).
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
+  // Measured alternatives (32 x 416 x 739 frames, 12 blocks): this symmetric 4-wave kernel, two workgroups per CU,
+  // 541 us; 8 waves with the tap loads of slab s+1 issued ahead of the MFMAs of slab s (208 VGPRs, one workgroup per CU,
+  // 306 tiles -> two rounds) 631 us.
+  constexpr int BN = WAVES_M * WM_TILES * 32;   // output channels per workgroup
+  constexpr int BM = WAVES_N * WN_TILES * 32;   // pixels per workgroup
+  constexpr int QA = BN / 32;
+  constexpr int RP = BM / 32;                   // pixel rows computed per thread per slab (thread = (row % 32, chunk))
+  constexpr int STAGE = (BN + BM) * 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int n_ct = p.coutp / BN;
+  const int bid = blockIdx.x;
+  const int grp = bid >> 3, xcd = bid & 7;
+  const int ct = grp % n_ct;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
+  const int ct0 = ct * BN;
+  const int pt0 = pt * BM;
+  const int HoWo = p.Ho * p.Wo;
+
+  // weight rows: DMA, lane -> (row = t*8 + lane/8, physical chunk lane%8), logical chunk = pchunk ^ ((row>>1)&7)
+  const int pchunk = lane & 7;
+  const int lchunk = pchunk ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const char* a_src[QA];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int row = (q * 4 + wave) * 8 + (lane >> 3);
+    a_src[q] = (const char*)(p.w + ((size_t)(ct0 + row)) * 32 + lchunk * 4);
+  }
+  const size_t a_slab_bytes = (size_t)p.coutp * 128;
+
+  // pixel rows: thread -> chunk c4 = tid & 7 (4 channels of the slab), rows (tid >> 3) + 32 j
+  const int c4 = tid & 7;
+  const float* src[RP];
+#pragma unroll
+  for (int j = 0; j < RP; ++j) {
+    const int row = (tid >> 3) + 32 * j;
+    int pix = pt0 + row;
+    if (pix >= p.M) pix = 0;                      // clamp: the store is masked
+    const int img = pix / HoWo;
+    const int rem = pix - img * HoWo;
+    const int y = rem / p.Wo;
+    const int x = rem - y * p.Wo;
+    src[j] = p.in + (size_t)img * p.in_img + (size_t)(y * p.dw_stride) * p.in_row + (size_t)(x * p.dw_stride) * p.in_pix + p.in_off0;
+  }
+
+  auto produce = [&](int s, int stage) {
+    float* base = lds + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int t = q * 4 + wave;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + (size_t)s * a_slab_bytes), LDS_PTR(base + t * 256), 16, 0, 0);
+    }
+    const int ch = s * 32 + c4 * 4;
+    f32x4 w9[9], bias;
+    const bool real = ch < p.dw_c;
+    if (real) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w9[t] = *(const f32x4*)(p.dw_w + t * p.dw_c + ch);
+      bias = *(const f32x4*)(p.dw_bias + ch);
+    }
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (real) {
+        acc = bias;
+        f32x4 v[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = *(const f32x4*)(src[j] + (size_t)ky * p.in_row + (size_t)kx * p.in_pix + ch);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v[t][e], w9[t][e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+      }
+      *(f32x4*)(base + (BN + row) * 32 + ((c4 ^ ((row >> 1) & 7)) * 4)) = acc;
+    }
+  };
+
+  f32x16 acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+    for (int b = 0; b < WN_TILES; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int fcb = (lane >> 5) * 4;
+  const int a_row0 = wm * WM_TILES * 32 + frow;
+  const int b_row0 = BN + wn * WN_TILES * 32 + frow;
+
+  const int S = p.n_slabs;
+  produce(0, 0);
+  for (int s = 0; s < S; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // slab s (weights landed, pixel rows written); everyone is done reading the other stage
+    if (s + 1 < S) produce(s + 1, (s + 1) & 1);
+    const float* st = lds + (s & 1) * STAGE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int pc = ((fcb + g) ^ fsw) * 4;
+      f32x4 av[WM_TILES], bv[WN_TILES];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+#pragma unroll
+      for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int b = 0; b < WN_TILES; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+}
+
 // (img, y, x) of the pixels pt0 + d of a tile, without a full integer division per lane: the tile's first pixel is
 // decomposed once (wave-uniform), every other pixel is d < 65536 further in raster order, so its carries are small
 // quotients that an f32 multiply by the reciprocal gets right to +-1 (fixed up exactly).
@@ -1160,6 +1299,32 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
+  constexpr int BN = WAVES_M * WM_TILES * 32;
+  constexpr int BM = WAVES_N * WN_TILES * 32;
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int groups = ((n_pt + 7) / 8) * n_ct;
+  const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
+  auto kern = conv_dwpw<WAVES_M, WAVES_N, WM_TILES, WN_TILES>;
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
+  if (p.M <= 0) return TA_OK;
+  if (p.prec != PREC_F32 || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w || !p.dw_bias ||
+      p.n_slabs * 32 < p.dw_c)
+    return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 mode, float32 activations and 4-aligned channels");
+  ta_prof_scope scope(ctx, 0, flops);
+  if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2>(ctx, p);
+  if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1>(ctx, p);
+  return launch_dwpw_cfg<1, 4, 1, 1>(ctx, p);
 }
 
 // ---- kernel selection ---------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 // reuse: 288 GB of HBM makes liveness packing pointless and the zero halos must stay intact),
 // and builds the per-conv K-offset tables.  Running is then a straight sequence of launches on
 // the context's stream.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -119,6 +120,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
 
   auto resolve_alias = [&](int id) -> int {
     const int src = m->tdesc[id].alias_of;
+    if (src == -2) ts[id].owns = false;            // shape only
     if (src < 0 || set[id]) return TA_OK;
     if (!set[src]) return ta_fail(ctx, TA_E_INVALID, "plan: alias tensor %d used before its source %d", id, src);
     if (ts[src].halo != 0 || (size_t)ts[src].h * ts[src].w * ts[src].c != (size_t)ts[id].c)
@@ -165,6 +167,18 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
       case TA_OP_MAXPOOL:
         TA_TRY(set_out(op.out, ti.h / 2, ti.w / 2));
         break;
+      case TA_OP_RFSTEM:
+        if (oi != 0 || op.in != in_id || m->tdesc[op.in].alias_of != -2 || op.w_off < 0)
+          return ta_fail(ctx, TA_E_INVALID, "plan: the RetinaFace front op must be op 0 on a shape-only input tensor");
+        TA_TRY(set_out(op.out, (ti.h + 1) / 2, (ti.w + 1) / 2));
+        break;
+      case TA_OP_DWPW:
+        if (ti.halo < 1) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu (dw+pw) needs an input halo", oi);
+        if (ti.fmt != TA_FMT_F32 || op.in_ch_off || op.scale2_off < 0 || op.shift2_off < 0 || op.cin > ti.c)
+          return ta_fail(ctx, TA_E_INVALID, "plan: op %zu: unsupported dw+pw block", oi);
+        TA_TRY(set_out(op.out, conv_out(ti.h, 3, op.stride, 1), conv_out(ti.w, 3, op.stride, 1)));
+        break;
+
       case TA_OP_COPYCH:
         TA_TRY(set_out(op.out, ti.h, ti.w));
         break;
@@ -204,7 +218,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
   for (int i = 0; i < T; ++i)
     if (set[i] && ts[i].owns) ts[i].dev = (float*)(np->arena + offs[i]);
   for (int i = 0; i < T; ++i)
-    if (set[i] && !ts[i].owns) ts[i].dev = ts[m->tdesc[i].alias_of].dev;
+    if (set[i] && !ts[i].owns) ts[i].dev = m->tdesc[i].alias_of >= 0 ? ts[m->tdesc[i].alias_of].dev : nullptr;
   np->splitk_ws = ws_bytes ? (float*)(np->arena + ws_off) : nullptr;
 
   // K-offset tables
@@ -243,12 +257,51 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
 
 static const float* wptr(const ta_model* m, int64_t off) { return off < 0 ? nullptr : (const float*)(m->weights_dev + off); }
 
+// tools only (TA_PROFILE_OPS=1): a HIP event pair around every op, then one table per forward on stderr
+static void print_op_profile(ta_model* m, std::vector<hipEvent_t>& ev) {
+  (void)hipStreamSynchronize(m->ctx->stream);
+  double tot_ms = 0, tot_fl = 0;
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const ta_op_desc& op = m->ops[oi];
+    const ta_tensor& to = m->tensors[op.out];
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev[2 * oi], ev[2 * oi + 1]);
+    const double M = (double)m->run_n * to.h * to.w;
+    const double fl = op.type == TA_OP_CONV ? 2.0 * op.macs_per_pixel * M : 0.0;
+    tot_ms += ms;
+    tot_fl += fl;
+    fprintf(stderr, "op %3zu type %d k%dx%d s%d g%d cin %4d cout %4d  %3dx%-3d M %8.0f slabs %4d  %8.1f us %7.1f TF\n", oi, op.type, op.kh,
+            op.kw, op.stride, op.groups, op.cin, op.cout, to.h, to.w, M, op.n_slabs, ms * 1e3, ms > 0 ? fl / (ms * 1e-3) / 1e12 : 0.0);
+  }
+  fprintf(stderr, "model kind %d n %d: %.3f ms in ops, %.1f GFLOP, %.1f TF\n", m->kind, m->run_n, tot_ms, tot_fl / 1e9, tot_fl / (tot_ms * 1e-3) / 1e12);
+  for (auto e : ev) (void)hipEventDestroy(e);
+}
+
 int ta_model_run_ops(ta_model* m) {
   ta_ctx* ctx = m->ctx;
+  static const bool prof_ops = getenv("TA_PROFILE_OPS") != nullptr;
+  std::vector<hipEvent_t> ev;
+  if (prof_ops) {
+    ev.resize(2 * m->ops.size());
+    for (auto& e : ev) (void)hipEventCreate(&e);
+  }
+  struct fin_t {
+    ta_model* m;
+    std::vector<hipEvent_t>& ev;
+    bool on;
+    ~fin_t() { if (on) print_op_profile(m, ev); }
+  } fin{m, ev, prof_ops};
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     const ta_op_desc& op = m->ops[oi];
     const ta_tensor& ti = m->tensors[op.in];
     const ta_tensor& to = m->tensors[op.out];
+    struct evp_t {
+      hipEvent_t e;
+      hipStream_t s;
+      bool on;
+      ~evp_t() { if (on) (void)hipEventRecord(e, s); }
+    } evp{prof_ops ? ev[2 * oi + 1] : nullptr, ctx->stream, prof_ops};
+    if (prof_ops) (void)hipEventRecord(ev[2 * oi], ctx->stream);
     switch (op.type) {
       case TA_OP_CONV: {
         ta_conv_launch p;
@@ -317,6 +370,43 @@ int ta_model_run_ops(ta_model* m) {
         TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
         break;
       }
+      case TA_OP_RFSTEM:
+        TA_TRY(ta_launch_rfstem(ctx, m->input_u8, m->run_n, ti.h, ti.w, (const float*)m->weights_host_small.data(), to));
+        break;
+      case TA_OP_DWPW: {
+        ta_conv_launch p;
+        memset(&p, 0, sizeof(p));
+        p.in = ti.dev;
+        p.w = wptr(m, op.w_off);
+        p.bias = wptr(m, op.bias_off);
+        p.dw_w = wptr(m, op.scale2_off);          // [9][cin]   (the op reuses the second-output fields for the depthwise part)
+        p.dw_bias = wptr(m, op.shift2_off);       // [cin]
+        p.dw_c = op.cin;
+        p.dw_stride = op.stride;
+        p.out = to.dev;
+        p.M = m->run_n * to.h * to.w;
+        p.Ho = to.h;
+        p.Wo = to.w;
+        p.n_slabs = op.n_slabs;
+        p.coutp = op.coutp;
+        p.cout = op.cout;
+        p.act = op.act;
+        p.stride = 1;
+        p.prec = op.prec;
+        p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
+        p.in_row = ti.wp() * ti.c;
+        p.in_pix = ti.c;
+        p.in_off0 = (int)(((size_t)(ti.halo - 1) * ti.wp() + (ti.halo - 1)) * ti.c);
+        p.in_fmt = ti.fmt;
+        p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
+        p.out_row = to.wp() * to.c;
+        p.out_pix = to.c;
+        p.out_off0 = (int)to.off(0, 0, 0);
+        p.out_ch = op.out_ch_off;
+        p.out_fmt = to.fmt;
+        TA_TRY(ta_launch_dwpw(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
+        break;
+      }
       case TA_OP_DWCONV: {
         ta_dw_launch p;
         memset(&p, 0, sizeof(p));
@@ -364,7 +454,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 2) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 3) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -391,6 +481,13 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0));
+    } else if (op.type == TA_OP_RFSTEM) {
+      bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
+    } else if (op.type == TA_OP_DWPW) {
+      bad = bad || op.w_off < 0 || op.bias_off < 0 || op.scale2_off < 0 || op.shift2_off < 0 || op.cin % 4 || op.cout % 4 ||
+            op.coutp % 32 || op.n_slabs <= 0 || op.n_slabs * 32 < op.cin || (op.stride != 1 && op.stride != 2) ||
+            bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) || bad_w(op.bias_off, (size_t)op.coutp * 4) ||
+            bad_w(op.scale2_off, (size_t)op.cin * 36) || bad_w(op.shift2_off, (size_t)op.cin * 4);
     } else if (op.type == TA_OP_DWCONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.kh != 3 || op.kw != 3 ||
             bad_w(op.w_off, (size_t)op.cin * 36) || bad_w(op.bias_off, (size_t)op.cin * 4);
@@ -411,6 +508,8 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     delete m;
     return ta_fail(ctx, TA_E_DEVICE, "weights upload failed: %s", hipGetErrorString(e));
   }
+  if (m->ops[0].type == TA_OP_RFSTEM)
+    m->weights_host_small.assign((const char*)blob + h.weights_off + m->ops[0].w_off, (const char*)blob + h.weights_off + m->ops[0].w_off + 448 * 4);
   *out = m;
   return TA_OK;
 }
@@ -434,8 +533,10 @@ int ta_model_forward_frames(ta_model* m, const ta_frames* f) {
     return ta_fail(ctx, TA_E_INVALID, "forward_frames: model kind %d takes crops", m->kind);
   if (f->n == 0) return TA_OK;
   TA_TRY(ta_model_plan(m, f->n, f->h, f->w));
-  TA_TRY(ta_launch_preprocess(ctx, m->kind == TA_MODEL_RETINAFACE ? TA_PRE_RETINAFACE : TA_PRE_OPENPOSE, f->dev, f->n,
-                              f->h, f->w, m->tensors[m->hdr.input_tensor]));
+  m->input_u8 = f->dev;
+  if (m->ops[0].type != TA_OP_RFSTEM)              // that op reads the frames itself
+    TA_TRY(ta_launch_preprocess(ctx, m->kind == TA_MODEL_RETINAFACE ? TA_PRE_RETINAFACE : TA_PRE_OPENPOSE, f->dev, f->n,
+                                f->h, f->w, m->tensors[m->hdr.input_tensor]));
   return ta_model_run_ops(m);
 }
 

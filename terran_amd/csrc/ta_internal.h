@@ -16,7 +16,14 @@
 // ---------------------------------------------------------------------------------------------
 #define TA_BLOB_MAGIC 0x314D4154u /* "TAM1" */
 
-enum { TA_OP_CONV = 1, TA_OP_DWCONV = 2, TA_OP_MAXPOOL = 3, TA_OP_COPYCH = 4 };
+enum {
+  TA_OP_CONV = 1,
+  TA_OP_DWCONV = 2,
+  TA_OP_MAXPOOL = 3,
+  TA_OP_COPYCH = 4,
+  TA_OP_RFSTEM = 5,   // RetinaFace front: uint8 frames -> conv3x3 s2 (3 -> 8) -> dw3x3 (8) -> 1x1 (8 -> 16), all + BN + ReLU, one kernel
+  TA_OP_DWPW = 6      // depthwise 3x3 (stride 1 / 2) + BN + ReLU fused into the following 1x1 conv + BN + ReLU (exact-f32 MFMA)
+};
 enum { TA_ACT_NONE = 0, TA_ACT_RELU = 1, TA_ACT_PRELU = 2 };
 
 struct ta_blob_header {
@@ -35,7 +42,8 @@ struct ta_blob_header {
 struct ta_tensor_desc {
   int32_t channels;   // C_total (multiple of 4)
   int32_t halo;
-  int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0)
+  int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0);
+                      // -2: shape only, never materialised (the float input of a program whose first op reads the frames)
   int32_t fmt;        // TA_FMT_F32 / TA_FMT_SPLIT (act_format.h)
 };
 
@@ -209,6 +217,10 @@ struct ta_conv_launch {
   int k_split;                                 // > 1: K is cut in k_split ranges, one workgroup each; raw sums go to
   float* partial;                              //      partial[k][pixel][coutp] and splitk_reduce_kernel finishes the op
   int variant;                                 // TA_CV_* this launch must use (0 = choose); an ineligible one is an error
+  // TA_OP_DWPW: the B operand is not DMA'd but computed -- depthwise 3x3 (+ bias, ReLU) of `in` at (y*dw_stride, x*dw_stride)
+  const float* dw_w;                           // [9][dw_c]
+  const float* dw_bias;                        // [dw_c]
+  int dw_c, dw_stride;
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
 };
@@ -224,6 +236,10 @@ static inline int ta_conv_ksplit(int coutp, int n_slabs, bool eligible) {
 }
 
 int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);
+int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p, double flops);
+struct ta_frames;
+// RetinaFace front kernel: frames (uint8 RGB) -> 16-channel float tensor at half resolution; 448 packed floats in HOST memory
+int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w, const float* weights_host, const struct ta_tensor& out);
 
 struct ta_dw_launch {
   const float* in;
@@ -264,6 +280,7 @@ struct ta_model {
   std::vector<ta_tensor_desc> tdesc;
   std::vector<ta_op_desc> ops;
   char* weights_dev = nullptr;
+  std::vector<char> weights_host_small;         // host copy of the few weights that travel as kernel arguments (TA_OP_RFSTEM)
   // small LRU of plans (lists of differently-sized images alternate between a few shapes); `tensors`,
   // `ktab_dev`, `ktab_off` mirror the active plan
   std::vector<ta_plan*> plans;
@@ -271,6 +288,7 @@ struct ta_model {
   uint64_t use_counter = 0;
   int plan_n = 0, plan_h = 0, plan_w = 0;      // plan_n = CAPACITY of the active plan (>= run_n)
   int run_n = 0;                                // images / crops of the current call: every launch covers run_n, not plan_n
+  const uint8_t* input_u8 = nullptr;            // the frames of the current forward_frames call (TA_OP_RFSTEM reads them)
   std::vector<ta_tensor> tensors;
   int32_t* ktab_dev = nullptr;
   std::vector<size_t> ktab_off;

@@ -19,7 +19,7 @@ import numpy as np
 from . import arch
 
 MODEL_RETINAFACE, MODEL_ARCFACE, MODEL_OPENPOSE = 1, 2, 3
-OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_COPYCH = 1, 2, 3, 4
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_COPYCH, OP_RFSTEM, OP_DWPW = 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
 MAGIC = 0x314D4154
 
@@ -37,7 +37,7 @@ _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 136 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 2            # 2: ta_op_desc grew `groups` (grouped convs)
+BLOB_VERSION = 3            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
@@ -84,7 +84,8 @@ class Program:
         self.allow_split = True
 
     def tensor(self, channels, halo, alias_of=-1, name=None, f32=False):
-        """f32=True pins the tensor to plain float32 (outputs read by post-processing kernels / the host)."""
+        """f32=True pins the tensor to plain float32 (outputs read by post-processing kernels / the host).
+        alias_of=-2: shape only, never materialised (the input of a program whose first op reads the frames itself)."""
         assert channels % 4 == 0
         self.tensors.append((channels, halo, alias_of))
         tid = len(self.tensors) - 1
@@ -162,6 +163,44 @@ class Program:
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
                   out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
+        op['in'] = tin
+        self.ops.append(op)
+
+    def rfstem(self, tin, tout, Ws, bs, Wd, bd, Wp, bp):
+        """RetinaFace front as ONE op: conv3x3 s2 (3 -> 8) -> depthwise 3x3 (8) -> 1x1 (8 -> 16), each + folded BN + ReLU.
+        Ws (8,3,3,3) / bs (8,), Wd (8,1,3,3) / bd (8,), Wp (16,8,1,1) / bp (16,), all already folded."""
+        blob = np.concatenate([np.asarray(Ws, np.float64).reshape(8, 27).ravel(), np.asarray(bs, np.float64),
+                               np.asarray(Wd, np.float64).reshape(8, 9).T.ravel(), np.asarray(bd, np.float64),
+                               np.asarray(Wp, np.float64).reshape(16, 8).ravel(), np.asarray(bp, np.float64)])
+        assert blob.size == 448
+        op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=16, coutp=32, kh=3, kw=3, stride=2,
+                  pad=1, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1,
+                  variant=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  macs_per_pixel=float(8 * 27 + 16 * 8))
+        op['in'] = tin
+        self.ops.append(op)
+
+    def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1):
+        """Depthwise 3x3 (stride 1 / 2, pad 1) + ReLU fused into the following 1x1 conv + ReLU (both BN-folded):
+        Wd (C,1,3,3) / bd (C,), Wp (cout, C, 1, 1) / bp (cout,).  Exact-f32 MFMA only."""
+        assert self.prec == 0, 'the fused depthwise + pointwise block exists in the f32 mode only'
+        C = Wd.shape[0]
+        Wp = np.asarray(Wp, np.float64)
+        cout = Wp.shape[0]
+        assert Wp.shape[1] == C and C % 4 == 0 and cout % 4 == 0
+        coutp = _rup(cout, 32)
+        n_slabs = _rup(C, 32) // 32
+        flat = np.zeros((n_slabs * 32, coutp), np.float32)
+        flat[:C, :cout] = Wp.reshape(cout, C).T
+        packed = np.ascontiguousarray(flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1))      # [slab][cout][32]
+        bias = np.zeros(coutp, np.float32)
+        bias[:cout] = np.asarray(bp, np.float64)
+        w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
+        op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
+                  stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
+                  n_slabs=n_slabs, prec=0, groups=1, variant=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  scale2_off=self._w(w9), shift2_off=self._w(np.asarray(bd, np.float64)),
+                  macs_per_pixel=float(cout * C))
         op['in'] = tin
         self.ops.append(op)
 
@@ -415,10 +454,13 @@ def pack_arcface(sd, precision='f32'):
 # ---- RetinaFace ----------------------------------------------------------------------------
 # Context tensor channel layout (96): ctx3x3 0..31 | reducer 32..47 | ctx5x5 48..63 | 7x7-mid 64..79 |
 # ctx7x7 80..95; the merged head conv reads all 96 with zero weights on reducer / 7x7-mid.
-def pack_retinaface(sd, precision='f32'):
+def pack_retinaface(sd, precision='f32', fused=None):
     """retinaface/model.py:53-316.  Sibling convs that share an input are merged (ctx3x3+reducer,
     ctx5x5+ctx7x7.0, cls+bbox+landmark heads); the FPN nearest-x2 upsample + add is the
-    residual of the lateral 1x1 conv's epilogue."""
+    residual of the lateral 1x1 conv's epilogue.  fused (default in the parity modes): the MobileNet base runs as
+    one front kernel (frames -> conv3x3 s2 -> dw3x3 -> 1x1) followed by 12 [depthwise 3x3 -> 1x1] blocks whose depthwise
+    output never leaves the CU (27 launches and a float copy of the frames become 13 launches);
+    fused=False keeps the layer-by-layer program (the `stem` debug tap; the `bf16` throughput mode)."""
     # The detector's outputs are decisions (score >= 0.5, IoU > 0.4, descending-score ORDER among ~10^2 near-equal
     # scores per image): measured over 208 frames, bf16x3 convs (2^-16 per product) kept every detection but swapped the
     # order of near-tied scores in 3 % of the images.  The graph is HBM-bound (35 FLOP/B), so the exact-f32 MFMA costs
@@ -426,7 +468,9 @@ def pack_retinaface(sd, precision='f32'):
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
     P = Program(MODEL_RETINAFACE, 'f32' if precision == 'bf16x3' else precision)
     P.allow_split = False
-    tin = P.tensor(4, 1, name='input')
+    if fused is None:
+        fused = P.prec == 0 and not os.environ.get('TERRAN_AMD_NO_FUSED_DETECTOR')       # A/B switch
+    tin = P.tensor(4, 1, alias_of=-2 if fused else -1, name='input')
     P.input_tensor = tin
     eps = arch.RETINA_BASE_BN_EPS
 
@@ -434,35 +478,47 @@ def pack_retinaface(sd, precision='f32'):
         s, sh = _bn_affine(sd, key_bn, e)
         return _fold(sd[key_conv + '.weight'], sd[key_conv + '.bias'] if bias else None, s, sh)
 
-    W, b = cbr('base.first_conv_block.0', 'base.first_conv_block.1')
-    a0 = P.tensor(8, 1)
-    P.conv(tin, a0, W, b, stride=2, act=ACT_RELU)
-    W, b = cbr('base.first_conv_block.3', 'base.first_conv_block.4')
-    t = P.tensor(8, 0, name='stem')
-    P.dwconv(a0, t, W, b)
+    # the base network as a chain: stem conv, then alternating depthwise / pointwise layers
+    pw_keys = [('base.scales.%d.%d.conv_block.0' % (si, bi), 'base.scales.%d.%d.conv_block.1' % (si, bi), cout, both)
+               for si, scale in enumerate(arch.RETINA_SCALES) for bi, (cin, cout, stride, both) in enumerate(scale)]
+    pw_keys += [('base.final_conv.0.conv_block.0', 'base.final_conv.0.conv_block.1', 256, False),
+                ('base.final_conv.1', 'base.final_conv.2', 256, True)]
+    dw_keys = [('base.first_conv_block.3', 'base.first_conv_block.4', 1)]
+    dw_keys += [('base.scales.%d.%d.sep_block.0' % (si, bi), 'base.scales.%d.%d.sep_block.1' % (si, bi), stride)
+                for si, scale in enumerate(arch.RETINA_SCALES) for bi, (cin, cout, stride, both) in enumerate(scale)]
+    dw_keys += [('base.final_conv.0.sep_block.0', 'base.final_conv.0.sep_block.1', 1)]
+    assert len(pw_keys) == len(dw_keys) == 13
     feats = []
-    for si, scale in enumerate(arch.RETINA_SCALES):
-        for bi, (cin, cout, stride, both) in enumerate(scale):
-            p = 'base.scales.%d.%d' % (si, bi)
-            W, b = cbr(p + '.conv_block.0', p + '.conv_block.1')
-            c = P.tensor(cout, 1)
-            P.conv(t, c, W, b, act=ACT_RELU)
-            W, b = cbr(p + '.sep_block.0', p + '.sep_block.1')
-            t = P.tensor(cout, 0)
-            P.dwconv(c, t, W, b, stride=stride)
+    if fused:
+        Ws, bs = cbr('base.first_conv_block.0', 'base.first_conv_block.1')
+        t = None
+        for i, ((dk, dbn, stride), (pk, pbn, cout, both)) in enumerate(zip(dw_keys, pw_keys)):
+            Wd, bd = cbr(dk, dbn)
+            Wp, bp = cbr(pk, pbn)
+            c = P.tensor(cout, 1 if i < 12 else 0)
+            if i == 0:
+                P.rfstem(tin, c, Ws, bs, Wd, bd, Wp, bp)
+            else:
+                P.dwpw(t, c, Wd, bd, Wp, bp, stride=stride)
             if both:
                 feats.append(c)
-    p = 'base.final_conv.0'
-    W, b = cbr(p + '.conv_block.0', p + '.conv_block.1')
-    c = P.tensor(256, 1)
-    P.conv(t, c, W, b, act=ACT_RELU)
-    W, b = cbr(p + '.sep_block.0', p + '.sep_block.1')
-    t = P.tensor(256, 0)
-    P.dwconv(c, t, W, b)
-    W, b = cbr('base.final_conv.1', 'base.final_conv.2')
-    f32 = P.tensor(256, 0)
-    P.conv(t, f32, W, b, act=ACT_RELU)
-    f8, f16 = feats
+            t = c
+    else:
+        W, b = cbr('base.first_conv_block.0', 'base.first_conv_block.1')
+        a0 = P.tensor(8, 1)
+        P.conv(tin, a0, W, b, stride=2, act=ACT_RELU)
+        t = a0
+        for i, ((dk, dbn, stride), (pk, pbn, cout, both)) in enumerate(zip(dw_keys, pw_keys)):
+            W, b = cbr(dk, dbn)
+            d = P.tensor(P.tensors[t][0], 0, name='stem' if i == 0 else None)
+            P.dwconv(t, d, W, b, stride=stride)
+            W, b = cbr(pk, pbn)
+            c = P.tensor(cout, 1 if i < 12 else 0)
+            P.conv(d, c, W, b, act=ACT_RELU)
+            if both:
+                feats.append(c)
+            t = c
+    f8, f16, f32 = feats
     P.tap('feat8', f8, 0, 64)
     P.tap('feat16', f16, 0, 128)
     P.tap('feat32', f32, 0, 256)

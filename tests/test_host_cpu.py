@@ -92,7 +92,7 @@ def test_pack_programs_are_well_formed(states):
         assert hdr['magic'] == pack.MAGIC and hdr['n_ops'] == len(P.ops)
         assert hdr['weights_off'] % 256 == 0 and hdr['weights_off'] + hdr['weights_bytes'] == len(blob)
         ops = np.frombuffer(blob[hdr['ops_off']:hdr['ops_off'] + pack.OP_DT.itemsize * len(P.ops)], pack.OP_DT)
-        conv = ops[ops['type'] == pack.OP_CONV]
+        conv = ops[(ops['type'] == pack.OP_CONV) | (ops['type'] == pack.OP_DWPW)]
         assert np.all(conv['coutp'] % 32 == 0) and np.all(conv['cin'] % 4 == 0) and np.all(conv['n_slabs'] > 0)
     # algorithmic MACs match SURVEY.md Appendix A (conv + linear, per image / crop)
     def macs(P, h, w):
@@ -105,6 +105,12 @@ def test_pack_programs_are_well_formed(states):
                 oh = (ih + 2 * op['pad'] - op['kh']) // op['stride'] + 1
                 ow = (iw + 2 * op['pad'] - op['kw']) // op['stride'] + 1
                 total += op['macs_per_pixel'] * oh * ow
+            elif op['type'] == pack.OP_RFSTEM:                     # conv3x3 s2 + depthwise (8 ch) + 1x1, one op
+                oh, ow = (ih + 1) // 2, (iw + 1) // 2
+                total += (op['macs_per_pixel'] + 72) * oh * ow
+            elif op['type'] == pack.OP_DWPW:                       # depthwise 3x3 (stride) + 1x1, one op
+                oh, ow = (ih - 1) // op['stride'] + 1, (iw - 1) // op['stride'] + 1
+                total += (op['macs_per_pixel'] + 9 * op['cin']) * oh * ow
             elif op['type'] == pack.OP_MAXPOOL:
                 oh, ow = ih // 2, iw // 2
             else:
@@ -115,7 +121,8 @@ def test_pack_programs_are_well_formed(states):
         return total
     assert abs(macs(pack.pack_openpose(states('openpose')), 368, 656) / 242.32e9 - 1) < 2e-3
     assert abs(macs(pack.pack_arcface(states('arcface')), 112, 112) / 12.090e9 - 1) < 2e-3
-    assert abs(macs(pack.pack_retinaface(states('retinaface')), 640, 640) / 981.1e6 - 1) < 5e-3
+    assert abs(macs(pack.pack_retinaface(states('retinaface')), 640, 640) / 981.1e6 - 1) < 5e-3             # fused program
+    assert abs(macs(pack.pack_retinaface(states('retinaface'), fused=False), 640, 640) / 981.1e6 - 1) < 5e-3
 
 
 def test_shard_bounds():
