@@ -904,6 +904,44 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     sh0 = *(const f32x4*)(p.shift2 + co);
     sh1 = *(const f32x4*)(p.shift2 + co + 4);
   }
+  if (p.pool) {
+    // 2x2 max-pool in the epilogue: rows 4 w .. 4 w + 3 of the staged tile are the four pixels of window w and sit in lanes
+    // G and 2 G apart (same 8 channels): two shuffle-max steps, then the window's first lane stores the pooled pixel.
+    // (bias and ReLU are applied first -- the values the separate pool kernel would have read.)
+    static_assert(4 * G <= 64 && (RPI & 3) == 0, "a window's four rows live in one wave");
+    const ta_pixel_walk walk(p, pt0 >> 2, HoWo);
+    for (int row = r0; row < BM; row += RPI) {
+      if (pt0 + row >= p.M) break;                   // M is a multiple of 4: whole windows drop out together
+      const int sw = row & (NCH - 1);
+      ta_f32x8 v;
+      v.a = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
+      v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] += bias0[e];
+        v.b[e] += bias1[e];
+        if (p.act == TA_ACT_RELU) {
+          v.a[e] = v.a[e] > 0.f ? v.a[e] : 0.f;
+          v.b[e] = v.b[e] > 0.f ? v.b[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int m = G; m <= 2 * G; m <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v.a[e] = fmaxf(v.a[e], __shfl_xor(v.a[e], m));
+          v.b[e] = fmaxf(v.b[e], __shfl_xor(v.b[e], m));
+        }
+      if ((row & 3) == 0) {
+        int img, qy, qx;
+        walk.at(row >> 2, img, qy, qx);
+        float* o = p.out + (size_t)img * p.out_img + (size_t)qy * p.out_row + (size_t)qx * p.out_pix + p.out_off0;
+        if (n4 == 2) ta_st8(o, p.out_ch + co, p.out_fmt, v);
+        else ta_st4(o, p.out_ch + co, p.out_fmt, v.a);
+      }
+    }
+    return;
+  }
   int pix = pt0 + r0;
   int img, y, x;
   ta_pixel_walk(p, pt0, HoWo).at(r0, img, y, x);
@@ -1038,16 +1076,23 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     issue_a(0, 0);
     if (S > 1) issue_a(1, 1);
     // pixel rows: offsets relative to the tile's first pixel (pixels of a tile ascend in raster order)
-    const ta_pixel_walk walk(p, pt0, HoWo);
+    // fused max-pool: the walk runs over 2x2 windows (pooled map), pixel d of the tile is position (d >> 1 & 1, d & 1) of window d >> 2
+    const int pl = p.pool;
+    const ta_pixel_walk walk(p, pl ? pt0 >> 2 : pt0, HoWo);
     const int in_ch = p.in_ch_off + (p.group_cout ? (ct0 / p.group_cout) * p.group_cin : 0);   // grouped conv: this tile's group
-    const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)(walk.y0 * p.stride) * p.in_row +
-                        (size_t)(walk.x0 * p.stride) * p.in_pix + p.in_off0 + in_ch;
+    const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)((walk.y0 << pl) * p.stride) * p.in_row +
+                        (size_t)((walk.x0 << pl) * p.stride) * p.in_pix + p.in_off0 + in_ch;
     const char* b_base = (const char*)(p.in + off0);
 #pragma unroll
     for (int q = QA; q < NI; ++q) {
       const int d = (q * NP + pw) * 8 + (lane >> 3) - BN;   // pixel row of the stage image
       int img, y, x;
-      walk.at(pt0 + d < p.M ? d : 0, img, y, x);
+      const int dd = pt0 + d < p.M ? d : 0;
+      walk.at(pl ? dd >> 2 : dd, img, y, x);
+      if (pl) {
+        y = 2 * y + ((dd >> 1) & 1);
+        x = 2 * x + (dd & 1);
+      }
       const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row + (size_t)(x * p.stride) * p.in_pix +
                          p.in_off0 + in_ch;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
@@ -1406,7 +1451,13 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
     if (!variant_eligible(v, p)) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
   }
   const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4;
-  if (!is_split) p.k_split = 1;                                              // only the split-role kernel knows K ranges
+  if (!is_split) p.k_split = 1;
+  if (p.pool) {                                      // only the split-role kernel's LDS-staged epilogue knows 2x2 windows
+    if (!is_split || p.res || p.out2 || (p.out_ch & 7) || (p.M & 3) || (p.act != TA_ACT_RELU && p.act != TA_ACT_NONE))
+      return ta_fail(ctx, TA_E_INVALID, "conv: the fused max-pool needs the split-role kernel and a plain epilogue (variant %d)", v);
+    p.k_split = 1;
+    p.direct_epilogue = 0;
+  }                                              // only the split-role kernel knows K ranges
   ctx->conv_counts[v] += 1;
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {

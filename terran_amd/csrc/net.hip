@@ -161,6 +161,12 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
         [[fallthrough]];
       case TA_OP_DWCONV:
         if (ti.halo < op.pad) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu needs halo %d, tensor has %d", oi, op.pad, ti.halo);
+        if (op.type == TA_OP_CONV && op.pool) {      // 2x2 / 2 max-pool (floor) in the conv's epilogue
+          if (op.out2 >= 0 || op.res >= 0 || op.groups > 1 || op.cin % 32 || op.coutp % 64)
+            return ta_fail(ctx, TA_E_INVALID, "plan: op %zu: unsupported conv + max-pool fusion", oi);
+          TA_TRY(set_out(op.out, conv_out(ti.h, op.kh, op.stride, op.pad) / 2, conv_out(ti.w, op.kw, op.stride, op.pad) / 2));
+          break;
+        }
         TA_TRY(set_out(op.out, conv_out(ti.h, op.kh, op.stride, op.pad), conv_out(ti.w, op.kw, op.stride, op.pad)));
         if (op.out2 >= 0) TA_TRY(set_out(op.out2, ts[op.out].h, ts[op.out].w));
         break;
@@ -365,9 +371,16 @@ int ta_model_run_ops(ta_model* m) {
           p.group_cin = op.cin;
         }
         p.variant = op.variant;
+        double flops = 2.0 * op.macs_per_pixel * (double)p.M;
+        if (op.pool) {
+          p.pool = 1;
+          p.M = m->run_n * to.h * to.w * 4;            // the four pixels of every 2x2 window
+          flops = 2.0 * op.macs_per_pixel * (double)m->run_n * conv_out(ti.h, op.kh, op.stride, op.pad) *
+                  conv_out(ti.w, op.kw, op.stride, op.pad);   // algorithmic: the whole conv output, odd edge included
+        }
         p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt)) : 1;
         p.partial = m->splitk_ws;
-        TA_TRY(ta_launch_conv(ctx, p, 2.0 * op.macs_per_pixel * (double)p.M));
+        TA_TRY(ta_launch_conv(ctx, p, flops));
         break;
       }
       case TA_OP_RFSTEM:
@@ -454,7 +467,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 3) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 4) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)

@@ -61,11 +61,13 @@ struct ta_op_desc {
   int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (f32-class), 2 = bf16 (throughput)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
   int32_t variant;                    // 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests)
+  int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
+  int32_t reserved;
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
 
-static_assert(sizeof(ta_blob_header) == 128 && sizeof(ta_tensor_desc) == 16 && sizeof(ta_op_desc) == 136,
+static_assert(sizeof(ta_blob_header) == 128 && sizeof(ta_tensor_desc) == 16 && sizeof(ta_op_desc) == 144,
               "blob layout is shared with terran_amd/pack.py (HEADER_DT / TENSOR_DT / OP_DT)");
 
 // ---------------------------------------------------------------------------------------------
@@ -221,6 +223,10 @@ struct ta_conv_launch {
   const float* dw_w;                           // [9][dw_c]
   const float* dw_bias;                        // [dw_c]
   int dw_c, dw_stride;
+  // pool = 1 (split-role kernel only): tile pixels are ordered quad by quad -- pixel t of the launch is position
+  // (t >> 1 & 1, t & 1) of 2x2 window t >> 2, windows in raster order over the POOLED map (Ho x Wo here are the pooled
+  // sizes, M = 4 N Ho Wo) -- and the epilogue stores the max of every window instead of the four pixels
+  int pool;
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
 };

@@ -33,11 +33,11 @@ HEADER_DT = np.dtype({
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
 FMT_F32, FMT_SPLIT = 0, 1
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
-           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant']
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'reserved']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
-assert OP_DT.itemsize == 136 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 3            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`
+assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
+BLOB_VERSION = 4            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
@@ -110,20 +110,24 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None, groups=1, variant=0):
+             scale2=None, shift2=None, groups=1, variant=0, pool=False):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
         ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
         groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
         [in_ch_off + g cin_g, + cin_g) and writes output channels [out_ch_off + g cout_g, + cout_g); cin_g a multiple
         of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups).
         variant != 0 pins the conv to one kernel variant (lib.CONV_VARIANTS; parity tests): loading fails when that
-        kernel cannot run the layer."""
+        kernel cannot run the layer.
+        pool=True fuses the 2x2 / 2 max-pool that follows the conv (+ activation) into its epilogue: `tout` is the POOLED
+        tensor (split-role kernel only: cin % 32 == 0, cout % 64 == 0, plain epilogue)."""
         W = np.asarray(W, dtype=np.float64)
         cout, cin, kh, kw = W.shape
         if groups > 1:
             assert cout % groups == 0 and cin % 32 == 0 and (cout // groups) % 128 == 0 and ch_pos is None
         if pad is None:
             pad = kh // 2
+        if pool:
+            assert groups == 1 and res < 0 and out2 < 0 and stride == 1 and cin % 32 == 0 and cout % 64 == 0 and ch_pos is None
         if cin_p is None:
             cin_p = _rup(cin, 4)
         if ch_pos is None:
@@ -150,7 +154,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
-                  groups=groups, variant=variant, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, variant=variant, pool=int(bool(pool)), reserved=0, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -161,7 +165,7 @@ class Program:
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
-                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
@@ -175,7 +179,7 @@ class Program:
         assert blob.size == 448
         op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=16, coutp=32, kh=3, kw=3, stride=2,
                   pad=1, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1,
-                  variant=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  variant=0, pool=0, reserved=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
                   macs_per_pixel=float(8 * 27 + 16 * 8))
         op['in'] = tin
         self.ops.append(op)
@@ -198,7 +202,7 @@ class Program:
         w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=0, groups=1, variant=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  n_slabs=n_slabs, prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
                   scale2_off=self._w(w9), shift2_off=self._w(np.asarray(bd, np.float64)),
                   macs_per_pixel=float(cout * C))
         op['in'] = tin
@@ -207,7 +211,7 @@ class Program:
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
-                  prec=0, groups=1, variant=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
                   macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)
@@ -325,9 +329,14 @@ def pack_openpose(sd, precision='f32'):
     X0 = P.tensor(OP_XCH, 3, name='X0')
     X1 = P.tensor(OP_XCH, 3, name='X1')
     items = arch.OPENPOSE_MODEL0
+    fuse_pool = not os.environ.get('TERRAN_AMD_NO_FUSED_POOL')     # A/B switch: separate max-pool launches
+    skip_pool = False
     for i, item in enumerate(items):
         nxt = items[i + 1] if i + 1 < len(items) else None
         if item[0] == 'pool':
+            if skip_pool:                                           # already done in the previous conv's epilogue
+                skip_pool = False
+                continue
             o = P.tensor(P.tensors[t][0], 1)
             P.simple(OP_MAXPOOL, t, o)
             t = o
@@ -337,6 +346,14 @@ def pack_openpose(sd, precision='f32'):
         if nxt is None:       # conv4_4_CPM -> feature slice of X0
             P.conv(t, X0, W, b, act=ACT_RELU, out_ch_off=OP_FEAT)
             P.tap('feat', X0, OP_FEAT, 128)
+        elif nxt[0] == 'pool' and fuse_pool and cin % 32 == 0 and cout % 64 == 0:
+            # conv + ReLU + 2x2 max-pool in one launch: the full-resolution map (493 MB per 32 frames after conv1_2 at
+            # 184 x 327) is never written; max commutes with nothing here -- it is applied to the very values the
+            # separate pool would have read
+            o = P.tensor(cout, 1, name=name + '_pooled')
+            P.conv(t, o, W, b, act=ACT_RELU, pool=True)
+            t = o
+            skip_pool = True
         else:
             o = P.tensor(cout, 0 if nxt[0] == 'pool' else 1, name=name)
             P.conv(t, o, W, b, act=ACT_RELU)
@@ -378,13 +395,29 @@ def pack_openpose(sd, precision='f32'):
             o = P.tensor(2 * cout, l1[li + 1][3] // 2)
             P.conv(cur, o, W, b, act=ACT_RELU if relu else ACT_NONE, groups=2)
             cur = o
-        for br, layers in ((1, l1), (2, l2)):          # output convs: different widths (38 / 19), own slices of xout
-            name, cin, cout, k, relu = layers[-1]
-            key = 'model%d_%d.%s' % (st, br, name)
-            off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
-            P.conv(cur, xout, sd[key + '.weight'], sd[key + '.bias'], act=ACT_RELU if relu else ACT_NONE,
-                   in_ch_off=(br - 1) * cin, out_ch_off=off, cout_p=cp)
-            P.tap('stage%d_%s' % (st, 'paf' if br == 1 else 'hm'), xout, off, cout)
+        # Output convs (1x1 -> 38 PAF / 19 heat-map channels, adjacent slices 128..167 | 168..187 of xout).  Where both are
+        # linear and narrow (stages 2-5) they run as ONE launch: rows [PAF 38 + 2 zero | HM 19 + 1 zero] over all 2 cin input channels
+        # with zero weights on the other branch's half -- exact zeros, so every output keeps its bits.  Stage 6 keeps two
+        # launches: its heat-map conv is followed by a ReLU (the reference's `no_relu_layers` typo), its PAF conv is not.
+        (np_, cin, co1, k, r1), (nh, cin2, co2, k2, r2) = l1[-1], l2[-1]
+        if r1 == r2 and cin == cin2 <= 128 and not os.environ.get('TERRAN_AMD_NO_MERGED_OUTPUTS'):   # (stage 1: 2 x 512 inputs, no gain)
+            Wp, bp = np.asarray(sd['model%d_1.%s.weight' % (st, np_)]), np.asarray(sd['model%d_1.%s.bias' % (st, np_)])
+            Wh, bh = np.asarray(sd['model%d_2.%s.weight' % (st, nh)]), np.asarray(sd['model%d_2.%s.bias' % (st, nh)])
+            Wm = np.zeros((60, 2 * cin, 1, 1), np.float32)
+            bm = np.zeros(60, np.float32)
+            Wm[0:co1, :cin], bm[0:co1] = Wp, bp
+            Wm[40:40 + co2, cin:], bm[40:40 + co2] = Wh, bh
+            P.conv(cur, xout, Wm, bm, act=ACT_RELU if r1 else ACT_NONE, out_ch_off=OP_PAF, cout_p=60)
+            P.ops[-1]['macs_per_pixel'] = float((co1 + co2) * cin)          # algorithmic work: the two real convs
+        else:
+            for br, layers in ((1, l1), (2, l2)):
+                name, cin, cout, k, relu = layers[-1]
+                key = 'model%d_%d.%s' % (st, br, name)
+                off, cp = (OP_PAF, 40) if br == 1 else (OP_HM, 20)
+                P.conv(cur, xout, sd[key + '.weight'], sd[key + '.bias'], act=ACT_RELU if relu else ACT_NONE,
+                       in_ch_off=(br - 1) * cin, out_ch_off=off, cout_p=cp)
+        P.tap('stage%d_paf' % st, xout, OP_PAF, 38)
+        P.tap('stage%d_hm' % st, xout, OP_HM, 19)
     P.outputs = [X0]
     P.tap('pafs', X0, OP_PAF, 38)
     P.tap('heatmaps', X0, OP_HM, 19)

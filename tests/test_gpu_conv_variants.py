@@ -42,6 +42,10 @@ LAYERS = {
     'arc3x3_prelu': dict(n=64, h=28, w=28, c1=128, cout=128, k=3, act=2),
     # OpenPose VGG conv1_2 at the 1080p size: 3x3 64 -> 64 on 184 x 327 maps                           (model.py:41-57)
     'vgg3x3_64_c5': dict(n=8, h=184, w=327, c1=64, cout=64, k=3, act=1),
+    # conv + ReLU + 2x2 max-pool in one launch (pack.py `pool=True`; conv1_2 / conv2_2 / conv3_4 of the VGG front), odd sizes
+    'vgg3x3_64_pool_c5': dict(n=8, h=184, w=327, c1=64, cout=64, k=3, act=1, pool=True),
+    'vgg3x3_128_pool_c5': dict(n=8, h=92, w=163, c1=128, cout=128, k=3, act=1, pool=True),
+    'vgg3x3_256_pool_c5': dict(n=32, h=46, w=81, c1=256, cout=256, k=3, act=1, pool=True),
     # OpenPose stage output conv: 1x1 128 -> 38 into a channel slice of the 192-channel concat tensor
     'pose1x1_to_slice': dict(n=16, h=46, w=82, c1=128, cout=38, k=1, out_total=192, out_off=128, cout_p=40),
 }
@@ -64,6 +68,10 @@ CASES = [
     ('arc3x3_prelu', 'split_2x4', False), ('arc3x3_prelu', 'auto', False),
     ('vgg3x3_64_c5', 'split_1x4', False), ('vgg3x3_64_c5', 'pipe64', False), ('vgg3x3_64_c5', 'auto', False),
     ('pose1x1_to_slice', 'generic', True), ('pose1x1_to_slice', 'auto', False),
+    ('vgg3x3_64_pool_c5', 'split_1x4', False), ('vgg3x3_64_pool_c5', 'auto', False),
+    ('vgg3x3_128_pool_c5', 'split_2x2', False), ('vgg3x3_128_pool_c5', 'split_2x4', False), ('vgg3x3_128_pool_c5', 'split_1x4', False),
+    ('vgg3x3_128_pool_c5', 'auto', False),
+    ('vgg3x3_256_pool_c5', 'split_2x4', False), ('vgg3x3_256_pool_c5', 'split_2x2_p8', False), ('vgg3x3_256_pool_c5', 'auto', False),
 ]
 
 _ref_cache = {}
@@ -110,6 +118,8 @@ def test_conv_variant_at_bench_size(ctx, layer, variant, mid_f32, precision):
         scale2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
         shift2 = rng.normal(0, 0.2, cout).astype(np.float32)
         kw.update(out2=t3, scale2=scale2, shift2=shift2)
+    if L.get('pool'):
+        kw['pool'] = True
     P.conv(t1, t2, W2, b2, stride=stride, act=act, out_ch_off=out_off, cout_p=L.get('cout_p'), **kw)
     P.outputs = [t2]
     m = lib.Model(ctx, P)
@@ -131,6 +141,8 @@ def test_conv_variant_at_bench_size(ctx, layer, variant, mid_f32, precision):
             y = F.prelu(y, torch.from_numpy(prelu))
         if L.get('res'):
             y = y + torch.from_numpy(m.read('res'))
+        if L.get('pool'):
+            y = F.max_pool2d(y, 2, 2, 0)                               # floor: the odd last row / column drops out
         _ref_cache[key] = (mid.numpy().copy(), y.numpy())
     mid_ref, y = _ref_cache[key]
     assert np.array_equal(mid.numpy(), mid_ref)                       # same input as the cached reference saw
