@@ -105,6 +105,8 @@ def test_pack_programs_are_well_formed(states):
                 oh = (ih + 2 * op['pad'] - op['kh']) // op['stride'] + 1
                 ow = (iw + 2 * op['pad'] - op['kw']) // op['stride'] + 1
                 total += op['macs_per_pixel'] * oh * ow
+                if op['pool']:                                      # 2x2 max-pool fused into the conv's epilogue
+                    oh, ow = oh // 2, ow // 2
             elif op['type'] == pack.OP_RFSTEM:                     # conv3x3 s2 + depthwise (8 ch) + 1x1, one op
                 oh, ow = (ih + 1) // 2, (iw + 1) // 2
                 total += (op['macs_per_pixel'] + 72) * oh * ow
