@@ -1447,7 +1447,9 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
       return ta_fail(ctx, TA_E_INVALID, "conv: forced kernel variant %d cannot run this layer (cin-uniform %d, slabs %d, coutp %d, "
                      "input format %d, groups %d)", v, p.uniform_k, p.n_slabs, p.coutp, p.in_fmt, p.group_cout ? 1 : 0);
   } else {
-    v = ctx->conv_force && variant_eligible(ctx->conv_force, p) ? ctx->conv_force : choose_variant(p);
+    auto is_split_v = [](int x) { return x == TA_CV_SPLIT_2x2 || x == TA_CV_SPLIT_2x2_P8 || x == TA_CV_SPLIT_2x4 || x == TA_CV_SPLIT_1x4; };
+    const bool prefer = ctx->conv_force && variant_eligible(ctx->conv_force, p) && (!p.pool || is_split_v(ctx->conv_force));
+    v = prefer ? ctx->conv_force : choose_variant(p);
     if (!variant_eligible(v, p)) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
   }
   const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4;

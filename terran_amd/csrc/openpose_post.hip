@@ -138,8 +138,12 @@ static void cubic_axis(int in_size, std::vector<int>& idx, std::vector<float>& w
 }
 
 // ---- 2. peaks -------------------------------------------------------------------------------------
+// The x8 maps are never materialised for grouping: peaks and PAF samples evaluate the bicubic interpolation on demand
+// from the network-resolution maps staged in LDS, with exactly the tap order bicubic_kernel uses (which stays as the
+// debug tap ta_bicubic_x8 and is pinned bitwise to F.interpolate): no 430 MB write + re-read per 32 frames at 184 x 327.
 struct op_work {
-  const float* up;     // [N][57][H8][W8]
+  op_maps m;           // network-resolution maps (NHWC)
+  const float* wphase; // [8][4] cubic weights per output phase (same table for x and y: they depend on the phase only)
   int N, H8, W8;
   int* peak_cnt;       // [N][18]
   int* peak_yx;        // [N][18][OP_MAXP][2]
@@ -147,7 +151,6 @@ struct op_work {
   int* conn_cnt;       // [N][19]   (-1 = limb missing)
   int* conn_ij;        // [N][19][OP_MAXP][2]
   float* conn_sc;      // [N][19][OP_MAXP]
-  unsigned long long* cand;   // [N][19][OP_MAXC] sort keys
   int* overflow;       // [1] sticky flag
   double scale;
   int* out_cnt;        // [N]
@@ -155,60 +158,130 @@ struct op_work {
   double* out_sc;      // [N][OP_MAXH]
 };
 
-__global__ __launch_bounds__(1024) void peaks_kernel(const op_work w) {
-  __shared__ int wave_tot[16];
-  __shared__ int s_base;
+// ATen's 4-tap accumulation (see bicubic_kernel): fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1)))
+__device__ __forceinline__ float op_chain(float v0, float v1, float v2, float v3, const float4 w) {
+  float a = v1 * w.y;
+  a = __builtin_fmaf(v0, w.x, a);
+  a = __builtin_fmaf(v2, w.z, a);
+  a = __builtin_fmaf(v3, w.w, a);
+  return a;
+}
+
+__device__ __forceinline__ int op_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// value of the x8 map at (Y, X) from the low-resolution map `sm` (h x w, row-major, in LDS): horizontal chains on the four
+// source rows, then the vertical chain -- bit for bit what bicubic_kernel writes at that pixel
+__device__ __forceinline__ float op_up_at(const float* sm, int h, int w, int Y, int X, const float4* wph) {
+  const int j = Y >> 3, py = Y & 7, q = X >> 3, px = X & 7;
+  const int r0 = j - (py < 4 ? 2 : 1), c0 = q - (px < 4 ? 2 : 1);
+  const float4 xw = wph[px], yw = wph[py];
+  const int c[4] = {op_clamp(c0, w - 1), op_clamp(c0 + 1, w - 1), op_clamp(c0 + 2, w - 1), op_clamp(c0 + 3, w - 1)};
+  float rows[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* s = sm + op_clamp(r0 + r, h - 1) * w;
+    rows[r] = op_chain(s[c[0]], s[c[1]], s[c[2]], s[c[3]], xw);
+  }
+  return op_chain(rows[0], rows[1], rows[2], rows[3], yw);
+}
+
+// One workgroup per (image, part).  A thread takes one source cell (j, q): from its 5 x 5 neighbourhood it builds the
+// 10 x 10 patch of x8 values around the cell's 8 x 8 output block (the block plus the one-pixel ring the 4-neighbour test
+// needs: the ring pixels belong to phases 7 / 0 of the adjacent cells, which read the same 5 x 5 values), tests the 64
+// block pixels, and appends the peaks to an LDS list; the list is then sorted by pixel index = the reference's row-major
+// `nonzero` order (wrapper.py:241-262).
+#define PK_T 512
+__global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  const int h = w.m.h, wd = w.m.w;
+  float* sm = (float*)psm;                                         // h * wd
+  float4* wph = (float4*)(psm + (((size_t)h * wd * 4 + 15) & ~(size_t)15));   // 8
+  unsigned long long* cand = (unsigned long long*)(wph + 8);       // OP_MAXP
+  __shared__ int s_count;
   const int part = blockIdx.x % 18, img = blockIdx.x / 18;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float* m = w.up + ((size_t)img * 57 + 38 + part) * w.H8 * w.W8;
-  const int ih = w.H8 - 2, iw = w.W8 - 2;
-  const int total = ih > 0 && iw > 0 ? ih * iw : 0;
-  int* yx = w.peak_yx + ((size_t)img * 18 + part) * OP_MAXP * 2;
-  float* sc = w.peak_sc + ((size_t)img * 18 + part) * OP_MAXP;
-  if (tid == 0) s_base = 0;
+  const int tid = threadIdx.x;
+  const float* src = w.m.base + (size_t)img * w.m.img + w.m.off0;
+  for (int i = tid; i < h * wd; i += PK_T) sm[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt);
+  if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
+  if (tid == 0) s_count = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < total; t0 += 1024) {
-    const int t = t0 + tid;
-    bool pk = false;
-    float v = 0.f;
-    int y = 0, x = 0;
-    if (t < total) {
-      y = t / iw + 1;
-      x = t - (y - 1) * iw + 1;
-      const float* p = m + (size_t)y * w.W8 + x;
-      v = p[0];
-      pk = (v >= p[-w.W8]) && (v >= p[-1]) && (v >= p[w.W8]) && (v >= p[1]) && (v >= 0.1f);
+  const int H8 = w.H8, W8 = w.W8;
+  for (int cell = tid; cell < h * wd; cell += PK_T) {
+    const int j = cell / wd, q = cell - j * wd;
+    float s[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[r][k] = sm[op_clamp(j - 2 + r, h - 1) * wd + op_clamp(q - 2 + k, wd - 1)];
+    // patch column xx (0..9) = output column 8 q - 1 + xx: phase (xx + 7) & 7, source columns q - 2 + o .. with o = xx >= 5
+    float hz[5][10];
+#pragma unroll
+    for (int xx = 0; xx < 10; ++xx) {
+      const float4 xw = wph[(xx + 7) & 7];
+      const int o = xx >= 5 ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) hz[r][xx] = op_chain(s[r][o], s[r][o + 1], s[r][o + 2], s[r][o + 3], xw);
     }
-    const unsigned long long bal = __ballot(pk);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wv] = __popcll(bal);
-    __syncthreads();
-    int off = s_base;
-    for (int k = 0; k < wv; ++k) off += wave_tot[k];
-    if (pk) {
-      const int pos = off + before;
-      if (pos < OP_MAXP) {
-        yx[pos * 2] = y;
-        yx[pos * 2 + 1] = x;
-        sc[pos] = v;
+    float up[3][10];                                                // three consecutive patch rows
+#pragma unroll
+    for (int yy = 0; yy < 10; ++yy) {
+      const float4 yw = wph[(yy + 7) & 7];
+      const int o = yy >= 5 ? 1 : 0;
+#pragma unroll
+      for (int xx = 0; xx < 10; ++xx) up[yy % 3][xx] = op_chain(hz[o][xx], hz[o + 1][xx], hz[o + 2][xx], hz[o + 3][xx], yw);
+      if (yy >= 2) {                                               // rows yy-2, yy-1, yy are there: test row yy-1
+        const int Y = 8 * j + yy - 2;
+        if (Y >= 1 && Y <= H8 - 2) {
+          const float* a = up[(yy - 2) % 3];
+          const float* b = up[(yy - 1) % 3];
+          const float* c = up[yy % 3];
+#pragma unroll
+          for (int xx = 1; xx <= 8; ++xx) {
+            const int X = 8 * q + xx - 1;
+            const float v = b[xx];
+            if (X >= 1 && X <= W8 - 2 && v >= a[xx] && v >= b[xx - 1] && v >= c[xx] && v >= b[xx + 1] && v >= 0.1f) {
+              const int pos = atomicAdd(&s_count, 1);
+              if (pos < OP_MAXP) cand[pos] = ((unsigned long long)(unsigned)(Y * W8 + X) << 32) | __float_as_uint(v);
+            }
+          }
+        }
       }
     }
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int k = 0; k < 16; ++k) tot += wave_tot[k];
-      s_base += tot;
-    }
-    __syncthreads();
   }
-  if (tid == 0) {
-    int c = s_base;
-    if (c > OP_MAXP) {
-      atomicExch(w.overflow, 1);
-      c = OP_MAXP;
-    }
-    w.peak_cnt[img * 18 + part] = c;
+  __syncthreads();
+  int C = s_count;
+  if (C > OP_MAXP) {
+    if (tid == 0) atomicExch(w.overflow, 1);
+    C = OP_MAXP;
   }
+  int P = 1;
+  while (P < C) P <<= 1;
+  for (int i = C + tid; i < P; i += PK_T) cand[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int i = tid; i < P; i += PK_T) {
+        const int ixj = i ^ jj;
+        if (ixj > i) {
+          const unsigned long long a = cand[i], b = cand[ixj];
+          if ((a > b) == ((i & k) == 0)) {
+            cand[i] = b;
+            cand[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  int* yx = w.peak_yx + ((size_t)img * 18 + part) * OP_MAXP * 2;
+  float* sc = w.peak_sc + ((size_t)img * 18 + part) * OP_MAXP;
+  for (int i = tid; i < C; i += PK_T) {
+    const unsigned long long key = cand[i];
+    const int pix = (int)(unsigned)(key >> 32);
+    yx[i * 2] = pix / W8;
+    yx[i * 2 + 1] = pix - (pix / W8) * W8;
+    sc[i] = __uint_as_float((unsigned)(key & 0xFFFFFFFFull));
+  }
+  if (tid == 0) w.peak_cnt[img * 18 + part] = C;
 }
 
 // ---- 3. limb scoring + greedy matching --------------------------------------------------------------
@@ -221,8 +294,11 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* keys = (unsigned long long*)smem;               // OP_MAXC
   unsigned* seen = (unsigned*)(smem + (size_t)OP_MAXC * 8);           // OP_MAXP bits
-  int* wave_tot = (int*)(seen + OP_MAXP / 32);                        // 4 + 1
+  int* wave_tot = (int*)(seen + OP_MAXP / 32);                        // 4 + 1 (+ 3 pad)
   int& s_base = wave_tot[4];
+  float4* wph = (float4*)(wave_tot + 8);                              // 8 phase weight sets
+  float* smx = (float*)(wph + 8);                                     // the limb's two PAF channels at network resolution
+  float* smy = smx + w.m.h * w.m.w;
 
   const int limb = blockIdx.x % 19, img = blockIdx.x / 19;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -236,11 +312,18 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
   }
   const int* syx = w.peak_yx + ((size_t)img * 18 + ks) * OP_MAXP * 2;
   const int* dyx = w.peak_yx + ((size_t)img * 18 + kd) * OP_MAXP * 2;
-  const size_t plane = (size_t)w.H8 * w.W8;
-  const float* pafx = w.up + ((size_t)img * 57 + (c_map_idx[limb][0] - 19)) * plane;
-  const float* pafy = w.up + ((size_t)img * 57 + (c_map_idx[limb][1] - 19)) * plane;
   const float half_h = (float)(0.5 * (double)w.H8);
-
+  {
+    const int mh = w.m.h, mw = w.m.w;
+    const float* srcm = w.m.base + (size_t)img * w.m.img + w.m.off0;
+    const int chx = w.m.paf_ch + c_map_idx[limb][0] - 19, chy = w.m.paf_ch + c_map_idx[limb][1] - 19;
+    for (int i = tid; i < mh * mw; i += 256) {
+      const float* px = srcm + (size_t)(i / mw) * w.m.row + (size_t)(i % mw) * w.m.pix;
+      smx[i] = ta_ld1(px, chx, w.m.fmt);
+      smy[i] = ta_ld1(px, chy, w.m.fmt);
+    }
+    if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
+  }
   if (tid == 0) s_base = 0;
   __syncthreads();
   const int total = ns * nd;
@@ -262,8 +345,7 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
 #pragma unroll
       for (int k = 0; k < OP_NMID; ++k) {
         const int yy = lin_trunc(ay, by, stepy, k), xx = lin_trunc(ax, bx, stepx, k);
-        const size_t o = (size_t)yy * w.W8 + xx;
-        const float mid = pafx[o] * ux + pafy[o] * uy;
+        const float mid = op_up_at(smx, w.m.h, w.m.w, yy, xx, wph) * ux + op_up_at(smy, w.m.h, w.m.w, yy, xx, wph) * uy;
         tot = k == 0 ? mid : tot + mid;
         cnt += mid > 0.05f ? 1 : 0;
       }
@@ -484,19 +566,51 @@ static int upload_axis_tables(ta_ctx* ctx, int h, int w, char* dev, size_t* size
 
 static size_t rup256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// maps -> packed results on the host.  `up_out` (optional) receives the upsampled maps instead of grouping.
-static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale, int capacity, int32_t* counts,
-                              int32_t* keypoints, double* scores, int32_t* required, float* up_out_host) {
+// The 8 phase weight sets of the x8 cubic (A = -0.75, align_corners = False): they depend on the output phase only.
+static void phase_weights(float out[32]) {
+  std::vector<int> idx;
+  std::vector<float> wts;
+  cubic_axis(2, idx, wts);                       // 16 outputs: entries 8..15 are one interior period
+  memcpy(out, wts.data() + 32, 32 * sizeof(float));
+}
+
+
+// x8 upsample alone, into host memory (debug tap ta_bicubic_x8)
+static int op_upsample_dev(ta_ctx* ctx, const op_maps& m, int N, float* up_out_host) {
   const int H8 = m.h * 8, W8 = m.w * 8;
   const size_t up_bytes = rup256((size_t)N * 57 * H8 * W8 * 4);
   const size_t tab_bytes = rup256((size_t)(H8 + W8) * 32);
+  char* scr = nullptr;
+  TA_TRY(ta_scratch(ctx, up_bytes + tab_bytes, (void**)&scr));
+  size_t ts[2];
+  TA_TRY(upload_axis_tables(ctx, m.h, m.w, scr + up_bytes, ts));
+  const float* ywt = (const float*)(scr + up_bytes + ts[0]);
+  const float* xwt = (const float*)(scr + up_bytes + 2 * ts[0] + ts[1]);
+  float* up = (float*)scr;
+  if (N > 65535 || m.h > 65535) return ta_fail(ctx, TA_E_INVALID, "openpose: batch too large for one upsample launch");
+  const int strips = (m.w + BC_TW - 1) / BC_TW;
+  const int lw = (m.w < BC_TW ? m.w : BC_TW) + 4;
+  const size_t lds = (size_t)5 * 57 * (lw | 1) * sizeof(float);
+  TA_SET_LDS_ATTR(ctx, bicubic_kernel, (size_t)5 * 57 * ((BC_TW + 4) | 1) * sizeof(float));
+  // the x weights depend only on the phase x % 8: entries 8..15 of the table are an interior period
+  hipLaunchKernelGGL(bicubic_kernel, dim3(m.h, strips, N), dim3(256), lds, ctx->stream, m, N, up, ywt, xwt + (m.w >= 2 ? 32 : 0));
+  TA_HIP(ctx, hipGetLastError());
+  TA_HIP(ctx, hipMemcpyAsync(up_out_host, up, (size_t)N * 57 * H8 * W8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TA_OK;
+}
+
+// network-resolution maps -> packed results on the host
+static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale, int capacity, int32_t* counts,
+                              int32_t* keypoints, double* scores, int32_t* required) {
+  const int H8 = m.h * 8, W8 = m.w * 8;
   size_t off = 0;
   auto carve = [&](size_t b) {
     size_t o = off;
     off += rup256(b);
     return o;
   };
-  const size_t o_up = carve(up_bytes), o_tab = carve(tab_bytes);
+  const size_t o_wph = carve(128);
   const size_t o_pcnt = carve((size_t)N * 18 * 4), o_pyx = carve((size_t)N * 18 * OP_MAXP * 8), o_psc = carve((size_t)N * 18 * OP_MAXP * 4);
   const size_t o_ccnt = carve((size_t)N * 19 * 4), o_cij = carve((size_t)N * 19 * OP_MAXP * 8), o_csc = carve((size_t)N * 19 * OP_MAXP * 4);
   const size_t o_ovf = carve(256), o_ocnt = carve((size_t)N * 4), o_okp = carve((size_t)N * OP_MAXH * 54 * 4), o_osc = carve((size_t)N * OP_MAXH * 8);
@@ -504,36 +618,22 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   const size_t o_gkp = carve(cap * 54 * 4), o_gsc = carve(cap * 8);
   char* scr = nullptr;
   TA_TRY(ta_scratch(ctx, off, (void**)&scr));
-  size_t ts[2];
-  TA_TRY(upload_axis_tables(ctx, m.h, m.w, scr + o_tab, ts));
-  const int* ytab = (const int*)(scr + o_tab);
-  const float* ywt = (const float*)(scr + o_tab + ts[0]);
-  const int* xtab = (const int*)(scr + o_tab + 2 * ts[0]);
-  const float* xwt = (const float*)(scr + o_tab + 2 * ts[0] + ts[1]);
-  float* up = (float*)(scr + o_up);
   {
-    const size_t total = (size_t)N * 57 * H8 * W8;
-    ta_prof_scope scope(ctx, 3, (double)total * 4);
-    if (N > 65535 || m.h > 65535) return ta_fail(ctx, TA_E_INVALID, "openpose: batch too large for one upsample launch");
-    const int strips = (m.w + BC_TW - 1) / BC_TW;
-    const int lw = (m.w < BC_TW ? m.w : BC_TW) + 4;
-    const size_t lds = (size_t)5 * 57 * (lw | 1) * sizeof(float);
-    TA_SET_LDS_ATTR(ctx, bicubic_kernel, (size_t)5 * 57 * ((BC_TW + 4) | 1) * sizeof(float));
-    // the x weights depend only on the phase x % 8: entries 8..15 of the table are an interior period
-    hipLaunchKernelGGL(bicubic_kernel, dim3(m.h, strips, N), dim3(256), lds, ctx->stream, m, N, up, ywt,
-                       xwt + (m.w >= 2 ? 32 : 0));
-    (void)ytab;
-    (void)xtab;
-    TA_HIP(ctx, hipGetLastError());
+    void* pin = nullptr;
+    TA_TRY(ta_pinned(ctx, 128, &pin));
+    phase_weights((float*)pin);
+    TA_HIP(ctx, hipMemcpyAsync(scr + o_wph, pin, 128, hipMemcpyHostToDevice, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the pinned block is reused by later calls
   }
-  if (up_out_host) {
-    TA_HIP(ctx, hipMemcpyAsync(up_out_host, up, (size_t)N * 57 * H8 * W8 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return TA_OK;
-  }
+  const size_t map_bytes = (size_t)m.h * m.w * 4;
+  const size_t lds_peaks = ((map_bytes + 15) & ~(size_t)15) + 128 + (size_t)OP_MAXP * 8;
+  const size_t lds_limbs = (size_t)OP_MAXC * 8 + OP_MAXP / 8 + 32 + 128 + 2 * map_bytes;
+  if (lds_peaks > 150 * 1024 || lds_limbs > 150 * 1024)
+    return ta_fail(ctx, TA_E_OVERFLOW, "openpose: %d x %d maps do not fit the grouping kernels' LDS staging", m.h, m.w);
   op_work w;
   memset(&w, 0, sizeof(w));
-  w.up = up;
+  w.m = m;
+  w.wphase = (const float*)(scr + o_wph);
   w.N = N;
   w.H8 = H8;
   w.W8 = W8;
@@ -558,15 +658,16 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   ctx->pose_dbg.conn_ij = w.conn_ij;
   ctx->pose_dbg.conn_sc = w.conn_sc;
   {
-    ta_prof_scope scope(ctx, 3, (double)N * 18 * H8 * W8 * 4);
-    hipLaunchKernelGGL(peaks_kernel, dim3(N * 18), dim3(1024), 0, ctx->stream, w);
+    // algorithmic bytes: the 18 part maps are read once at network resolution
+    ta_prof_scope scope(ctx, 3, (double)N * 18 * m.h * m.w * 4);
+    TA_SET_LDS_ATTR(ctx, peaks_kernel, 150 * 1024);
+    hipLaunchKernelGGL(peaks_kernel, dim3(N * 18), dim3(PK_T), lds_peaks, ctx->stream, w);
     TA_HIP(ctx, hipGetLastError());
   }
   {
-    ta_prof_scope scope(ctx, 3, 0.0);
-    const size_t lds = (size_t)OP_MAXC * 8 + OP_MAXP / 8 + 64;
-    TA_SET_LDS_ATTR(ctx, limbs_kernel, lds);
-    hipLaunchKernelGGL(limbs_kernel, dim3(N * 19), dim3(256), lds, ctx->stream, w);
+    ta_prof_scope scope(ctx, 3, (double)N * 38 * m.h * m.w * 4);
+    TA_SET_LDS_ATTR(ctx, limbs_kernel, 150 * 1024);
+    hipLaunchKernelGGL(limbs_kernel, dim3(N * 19), dim3(256), lds_limbs, ctx->stream, w);
     TA_HIP(ctx, hipGetLastError());
   }
   {
@@ -648,7 +749,7 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
   mp.fmt = X.fmt;
   mp.h = X.h;
   mp.w = X.w;
-  return op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required, nullptr);
+  return op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required);
 }
 
 int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w, double scale,
@@ -675,7 +776,7 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
   mp.fmt = TA_FMT_F32;
   mp.h = h;
   mp.w = w;
-  const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required, nullptr);
+  const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(dev);
   return rc;
@@ -749,7 +850,7 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
     mp.h = h;
     mp.w = w;
     std::vector<float> up((size_t)n * 57 * 64 * h * w);
-    const int rc = op_postprocess_dev(ctx, mp, n, 1.0, 0, nullptr, nullptr, nullptr, nullptr, up.data());
+    const int rc = op_upsample_dev(ctx, mp, n, up.data());
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dev);
     if (rc != TA_OK) return rc;
