@@ -1,0 +1,86 @@
+"""Summaries of one profiles/collect.sh run (rocprofv3 rocpd sqlite outputs under <collect dir>):
+    python profiles/summarize_round.py gpurun_out/collect profiles/r02
+writes, per precision P in {bf16x3, f32}:
+  <prefix>_<P>_kernel_stats.csv     per-kernel totals of the --kernel-trace --stats run (bench.py --serial)
+  <prefix>_<P>_top_dispatches.csv   the 60 longest dispatches (grid, LDS, VGPRs, duration)
+  <prefix>_pmc_conv_<P>.json        HBM bytes of the conv kernels (FETCH_SIZE x2 + WRITE_SIZE, separate passes; the x2 is
+                                    the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md), effective shader clock
+                                    (GRBM_GUI_ACTIVE / 8 XCDs / kernel time) and MFMA busy share
+                                    (SQ_VALU_MFMA_BUSY_CYCLES / (busy cycles x 1024 SIMDs)) of the conv kernels
+Each PMC pass ran 3 steps (1 warm-up, 1 timed, 1 event-profiled)."""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+CONV_LIKE = ['%conv_igemm%', '%conv_dwpw%', '%rf_stem%']
+
+
+def find_db(d):
+    c = glob.glob(os.path.join(d, '**', '*_results.db'), recursive=True)
+    return c[0] if c else None
+
+
+def kernel_tables(db_path, prefix):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = list(cur.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
+    with open(prefix + '_kernel_stats.csv', 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'pct'])
+        for name, calls, total, avg, pct in rows:
+            w.writerow([name, calls, round(total / 1e3, 3) if total > 1e6 else round(total, 3), round(avg, 3), round(pct, 3)])   # ns -> us
+    disp = list(cur.execute('select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, '
+                            '(end-start) from kernels order by (end-start) desc limit 60'))
+    with open(prefix + '_top_dispatches.csv', 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'grid_x', 'workgroup_x', 'lds_bytes', 'vgpr', 'agpr', 'sgpr', 'duration_ns'])
+        w.writerows(disp)
+    conv = [(n, c, t) for n, c, t, _, _ in rows if 'conv_' in n or 'rf_stem' in n]
+    return {'conv_launches': sum(c for _, c, _ in conv), 'conv_total_ms': sum(t for _, _, t in conv) / 1e6,
+            'all_kernels_ms': sum(r[2] for r in rows) / 1e6, 'steps_in_trace': 5}
+
+
+def pmc_total(db_path, counter):
+    cur = sqlite3.connect(db_path).cursor()
+    v = ns = n = 0
+    for like in CONV_LIKE:
+        rows = cur.execute('select c.value, (k.end - k.start) from counters_collection c join kernels k on c.dispatch_id = k.dispatch_id '
+                           'where c.counter_name=? and c.kernel_name like ?', (counter, like)).fetchall()
+        v += sum(r[0] for r in rows)
+        ns += sum(r[1] for r in rows)
+        n += len(rows)
+    return float(v), float(ns), n
+
+
+def main(collect, prefix, steps=3):
+    for P in ('bf16x3', 'f32'):
+        kt = find_db(os.path.join(collect, 'kt_' + P))
+        out = {}
+        if kt:
+            out['kernel_trace'] = kernel_tables(kt, '%s_%s' % (prefix, P))
+        pm = {}
+        for C in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
+            db = find_db(os.path.join(collect, 'pmc_%s_%s' % (C, P)))
+            if db:
+                pm[C] = pmc_total(db, C)
+        res = {'kernels': 'conv_igemm* + conv_dwpw + rf_stem_kernel (every dense-conv launch)', 'steps_in_run': steps}
+        if 'FETCH_SIZE' in pm and 'WRITE_SIZE' in pm:
+            f, _, n = pm['FETCH_SIZE']
+            w, _, _ = pm['WRITE_SIZE']
+            res.update({'launches_per_step': n / steps, 'fetch_size_kib_per_step_raw': f / steps,
+                        'write_size_kib_per_step_raw': w / steps, 'fetch_correction': 2.0,
+                        'hbm_bytes_per_step': (2.0 * f + w) * 1024 / steps, 'hbm_bytes_per_launch': (2.0 * f + w) * 1024 / max(n, 1)})
+        if 'GRBM_GUI_ACTIVE' in pm and 'SQ_VALU_MFMA_BUSY_CYCLES' in pm:
+            cyc, ns, _ = pm['GRBM_GUI_ACTIVE']
+            busy, ns2, _ = pm['SQ_VALU_MFMA_BUSY_CYCLES']
+            res.update({'effective_clock_ghz': cyc / 8.0 / ns, 'conv_kernel_ms_per_step': ns / 1e6 / steps,
+                        'mfma_busy_frac_of_simd_cycles': (busy * (ns / ns2)) / (cyc / 8.0 * 1024.0)})
+        res.update(out)
+        json.dump(res, open('%s_pmc_conv_%s.json' % (prefix, P), 'w'), indent=1)
+        print(P, json.dumps(res))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

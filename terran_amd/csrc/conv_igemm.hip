@@ -358,6 +358,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
 }
 
+// K-slab order of the uniform-K kernels (conv_igemm_pipe, conv_igemm_split): channel block OUTERMOST, then ky, then kx.
+// A workgroup re-reads its input patch once per filter tap; with the channel block innermost (the packed weight order)
+// every slab touches another 128-byte block of every patch pixel, so the bytes a 128 x 256-pixel tile keeps coming back to
+// are the whole patch (150 KB at 23 x 40 x 128 ch; 32 co-resident tiles per XCD = 4.8 MB against a 4 MiB L2: measured
+// 2.8-4x the fabric reads of the 128 x 128 tiling, tools/fetch_probe.sh).  Walking all kh x kw taps of ONE channel block
+// before moving on shrinks that to 1 / cblocks of it.  Every uniform-K kernel uses this one order, so a layer's float
+// summation order -- and with it every output bit -- does not depend on which of them the launcher picks for a batch size.
+// Slab s' of the walk is packed weight slab (tap * cblocks + cb).  All scalar (wave-uniform) arithmetic.
+struct ta_k_walk {
+  int cb, kx, ky, b_off, a_slab;
+  int cblocks, kw, kh, pix_bytes, row_bytes;
+  __device__ __forceinline__ ta_k_walk(const ta_conv_launch& p, int s0) {
+    cblocks = p.k_cblocks;
+    kw = p.k_w;
+    kh = p.k_h;
+    pix_bytes = p.in_pix * 4;
+    row_bytes = p.in_row * 4;
+    const int taps = kw * kh;
+    cb = s0 / taps;
+    const int tap = s0 - cb * taps;
+    ky = tap / kw;
+    kx = tap - ky * kw;
+    b_off = cb * 128 + kx * pix_bytes + ky * row_bytes;
+    a_slab = tap * cblocks + cb;
+  }
+  __device__ __forceinline__ void advance() {
+    ++kx;
+    b_off += pix_bytes;
+    a_slab += cblocks;
+    if (kx == kw) {
+      kx = 0;
+      b_off += row_bytes - kw * pix_bytes;
+      if (++ky == kh) {
+        ky = 0;
+        ++cb;
+        b_off += 128 - kh * row_bytes;
+        a_slab = cb;
+      }
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Deep-pipelined variant for convs whose K slabs never straddle a filter tap (cin % 32 == 0: every heavy
 // layer).  Differences from conv_igemm above:
@@ -422,35 +464,20 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
   }
   const size_t a_slab_bytes = (size_t)p.coutp * 128;
 
-  // scalar walk over K: channel block (128 B) fastest, then kx, then ky
-  int k_cb = 0, k_x = 0;
-  int k_off = 0;                                  // byte offset of the next slab to issue
-  const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
-  auto advance = [&]() {
-    ++k_cb;
-    k_off += 128;
-    if (k_cb == p.k_cblocks) {
-      k_cb = 0;
-      k_off += pix_bytes - p.k_cblocks * 128;
-      if (++k_x == p.k_w) {
-        k_x = 0;
-        k_off += row_bytes - p.k_w * pix_bytes;
-      }
-    }
-  };
-  auto issue = [&](int s, int stage) {
+  ta_k_walk kw_(p, 0);                            // the next slab to issue (ta_k_walk: channel block outermost)
+  auto issue = [&](int, int stage) {
     float* base = lds + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int t = q * 4 + wave;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + (size_t)s * a_slab_bytes), LDS_PTR(base + t * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + (size_t)kw_.a_slab * a_slab_bytes), LDS_PTR(base + t * 256), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const int t = q * 4 + wave;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[q] + k_off), LDS_PTR(base + BN * 32 + t * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[q] + kw_.b_off), LDS_PTR(base + BN * 32 + t * 256), 16, 0, 0);
     }
-    advance();
+    kw_.advance();
   };
 
   f32x16 acc[WM_TILES][WN_TILES];
@@ -1068,9 +1095,11 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     unsigned b_off[NI - QA];
 #pragma unroll
     for (int q = 0; q < QA; ++q) a_off[q] = (unsigned)(((ct0 + (q * NP + pw) * 8 + (lane >> 3)) * 32 + lchunk * 4) * 4);
-    auto issue_a = [&](int s, int stage) {
+    ta_k_walk wa(p, s_begin);                       // weight rows and pixel rows are issued in the same slab order, the
+    auto issue_a = [&](int, int stage) {            // weight rows two slabs ahead at the start: two walkers
 #pragma unroll
-      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)(s_begin + s) * a_slab_bytes, a_off[q], lds + stage * STAGE + (q * NP + pw) * 256);
+      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)wa.a_slab * a_slab_bytes, a_off[q], lds + stage * STAGE + (q * NP + pw) * 256);
+      wa.advance();
     };
     // the weight rows of the first two slabs need no pixel arithmetic: get them moving first
     issue_a(0, 0);
@@ -1097,23 +1126,11 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
                          p.in_off0 + in_ch;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
     }
-    const int pix_bytes = p.in_pix * 4, row_bytes = p.in_row * 4;
-    int k_cb = s_begin % p.k_cblocks;               // K walk starts at slab s_begin: (channel block, kx, ky)
-    int k_x = (s_begin / p.k_cblocks) % p.k_w;
-    int k_off = k_cb * 128 + k_x * pix_bytes + (s_begin / p.k_cblocks / p.k_w) * row_bytes;
+    ta_k_walk wb(p, s_begin);
     auto issue_b = [&](int stage) {                 // pixel rows of the next slab in K order
 #pragma unroll
-      for (int q = QA; q < NI; ++q) ta_dma16(b_base + k_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
-      ++k_cb;
-      k_off += 128;
-      if (k_cb == p.k_cblocks) {
-        k_cb = 0;
-        k_off += pix_bytes - p.k_cblocks * 128;
-        if (++k_x == p.k_w) {
-          k_x = 0;
-          k_off += row_bytes - p.k_w * pix_bytes;
-        }
-      }
+      for (int q = QA; q < NI; ++q) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
+      wb.advance();
     };
     if (wave == NC) TA_STAMP(9);                    // producer: addresses ready
     issue_b(0);

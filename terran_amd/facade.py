@@ -42,6 +42,25 @@ def _merge(ctx, frame_list, canvas=None):
     return canvas, pads
 
 
+class ShardedFrames:
+    """A host frame batch uploaded ONCE across the devices of a fan-out: one resident `lib.Frames` per replica (its
+    contiguous sub-batch).  Returned by `Detection / Recognition / Estimation(device=[...]).upload(images)` and accepted
+    by all three facades built over the same device list, so detect, embed and pose share one PCIe upload per device."""
+
+    def __init__(self, parts, bounds, n):
+        self.parts, self.bounds, self.n = parts, bounds, n
+        self.shape = (n,) + tuple(parts[0].shape[1:]) if parts else (0, 0, 0, 3)
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        for p in self.parts:
+            if p is not None:
+                p.free()
+        self.parts = []
+
+
 class _Fanout:
     """SURVEY.md 8(e) inside ONE process: `device=[0, 1, ..., 7]` makes a facade a fan-out over one replica of itself
     per listed device -- its own context (HIP stream, scratch, pinned staging) and weights, driven by its own host
@@ -55,18 +74,32 @@ class _Fanout:
         self.devices = list(devices)
         if not self.devices:
             raise ValueError('`device` list is empty')
-        # replica 0 lives on the shared per-device context, further replicas (also on a repeated device) get their own
-        seen = set()
-        self.replicas = []
-        for d in self.devices:
-            idx = runtime.device_index(d)
-            ctx = runtime.get_context(idx) if idx not in seen else runtime.new_context(idx)
-            seen.add(idx)
-            self.replicas.append(make_replica(d, ctx))
+        # every replica gets a context of its own (stream, scratch, staging): replicas of different facades run at the
+        # same time on their own host threads, and a context belongs to one thread at a time
+        self.replicas = [make_replica(d, runtime.new_context(runtime.device_index(d))) for d in self.devices]
         self.pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix='terran_amd-device')
 
+    def upload(self, images):
+        """Scatter: every replica's thread uploads its contiguous sub-batch to its device -> ShardedFrames."""
+        images = np.asarray(images)
+        n, k = len(images), len(self.replicas)
+        bounds = [shard_bounds(n, k, r) for r in range(k)]
+        futs = [self.pool.submit(rep._ctx().upload, images[lo:hi]) if hi > lo else None
+                for rep, (lo, hi) in zip(self.replicas, bounds)]
+        return ShardedFrames([f.result() if f is not None else None for f in futs], bounds, n)
+
     def __call__(self, items, *per_item, **kw):
-        """items: ndarray batch or list; per_item: sequences aligned with it (sharded the same way); kw: passed on."""
+        """items: ndarray batch, list or ShardedFrames; per_item: sequences aligned with it (sharded the same way)."""
+        if isinstance(items, ShardedFrames):
+            if len(items.parts) != len(self.replicas):
+                raise ValueError('these frames were scattered over %d replicas, this facade has %d'
+                                 % (len(items.parts), len(self.replicas)))
+            futs = [self.pool.submit(rep, part, *[p[lo:hi] for p in per_item], **kw)
+                    for rep, part, (lo, hi) in zip(self.replicas, items.parts, items.bounds) if part is not None]
+            out = []
+            for f in futs:
+                out.extend(f.result())
+            return out
         if isinstance(items, lib.Frames):
             raise ValueError('a batch that is already resident on one device cannot be fanned out: pass host frames')
         n = len(items)
@@ -109,6 +142,15 @@ class Detection:
     def __repr__(self):
         return '<Detection(%s)>' % self.detection_cls.__name__
 
+    def _ctx(self):
+        if self.model is None:
+            self.model = self.detection_cls(device=self.device, **self._model_kw)
+        return self.model.ctx
+
+    def upload(self, images):
+        """Frames -> HBM once, for several facade calls: `lib.Frames`, or `ShardedFrames` when built over a device list."""
+        return self._fanout.upload(images) if self._fanout is not None else self._ctx().upload(images)
+
     def _resized(self, ctx, image_batch):
         """-> (lib.Frames at network resolution, scale).  `image_batch` may already be resident."""
         H, W = image_batch.shape[1:3]
@@ -122,12 +164,12 @@ class Detection:
             src.free()
 
     def __call__(self, images, _canvas=None):
-        expanded = not isinstance(images, lib.Frames) and _is_single(images)
+        expanded = not isinstance(images, (lib.Frames, ShardedFrames)) and _is_single(images)
         if expanded:
             images = np.expand_dims(images, 0)
         if self._fanout is not None:
             kw = {}
-            if not isinstance(images, np.ndarray):                      # list: every shard pads to the WHOLE list's canvas
+            if not isinstance(images, (np.ndarray, ShardedFrames)):     # list: every shard pads to the WHOLE list's canvas
                 if self._merge_error is not None:
                     raise self._merge_error
                 sizes = [(int(h * (self.short_side / min(h, w))), int(w * (self.short_side / min(h, w))))
@@ -190,9 +232,17 @@ class Recognition:
     def __repr__(self):
         return '<Recognition(%s)>' % self.recognition_cls.__name__
 
+    def _ctx(self):
+        if self.model is None:
+            self.model = self.recognition_cls(device=self.device, **self._model_kw)
+        return self.model.ctx
+
+    def upload(self, images):
+        return self._fanout.upload(images) if self._fanout is not None else self._ctx().upload(images)
+
     def __call__(self, images, faces_per_image=None):
         expanded = False
-        if _is_single(images):
+        if not isinstance(images, (lib.Frames, ShardedFrames)) and _is_single(images):
             expanded = True
             images = [images]
             faces_per_image = [[faces_per_image]] if isinstance(faces_per_image, dict) else [faces_per_image]
@@ -200,7 +250,7 @@ class Recognition:
             raise ValueError('`images` and `faces_per_image` must be of the same size, but the former is of size '
                              '%d while the latter of size %d.' % (len(images), len(faces_per_image)))
         if self._fanout is not None and faces_per_image is not None:
-            out = self._fanout(list(images), list(faces_per_image))
+            out = self._fanout(images if isinstance(images, ShardedFrames) else list(images), list(faces_per_image))
             if any(len(f) for f in faces_per_image):                    # a shard without faces answers float64 (0,512)
                 out = [o.astype(np.float32) if o.shape[0] == 0 else o for o in out]   # (wrapper.py:160-164); 1-way: float32
             return out[0] if expanded else out
@@ -236,13 +286,21 @@ class Estimation:
     def __repr__(self):
         return '<Estimation(%s)>' % self.estimation_cls.__name__
 
+    def _ctx(self):
+        if self.model is None:
+            self.model = self.estimation_cls(device=self.device, short_side=self.short_side, **self._model_kw)
+        return self.model.ctx
+
+    def upload(self, images):
+        return self._fanout.upload(images) if self._fanout is not None else self._ctx().upload(images)
+
     def __call__(self, images, _canvas=None):
-        expanded = not isinstance(images, lib.Frames) and _is_single(images)
+        expanded = not isinstance(images, (lib.Frames, ShardedFrames)) and _is_single(images)
         if expanded:
             images = np.expand_dims(images, 0)
         if self._fanout is not None:
             kw = {}
-            if not isinstance(images, np.ndarray):
+            if not isinstance(images, (np.ndarray, ShardedFrames)):
                 if self._merge_error is not None:
                     raise self._merge_error
                 sizes = [np.asarray(im).shape[:2] for im in images]

@@ -629,5 +629,13 @@ def test_fanout_two_contexts_equal_one_way(states, precision):
     same(run(one, frames[:1], pframes[:1]), run(two, frames[:1], pframes[:1]))        # fewer frames than devices
     single = two[0](frames[0])
     assert isinstance(single, list) and (not single or isinstance(single[0], dict))
+    # one upload per device shared by the three facades (ShardedFrames)
+    sf, psf = two[0].upload(frames), two[2].upload(pframes)
+    dets = two[0](sf)
+    faces = [d[:2] for d in dets]
+    faces[0] = []
+    same(a, (dets, two[1](sf, faces), two[2](psf)))
+    sf.free()
+    psf.free()
     with pytest.raises(NotImplementedError):
         Detection(merge_method='crop', device=[0, 0], state=states('retinaface'))(lst)

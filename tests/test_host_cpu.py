@@ -229,7 +229,7 @@ def test_pack_cache_roundtrip(tmp_path, states, monkeypatch):
 def test_fanout_shards_contiguously_and_keeps_order(monkeypatch):
     """facade._Fanout (single-process multi-device) with stand-in replicas: contiguous shards in device
     order, sizes differing by at most one, aligned per-item arguments sharded alike, keyword arguments passed on,
-    devices beyond the batch size left idle, first replica of a device on the shared context and repeats on new ones."""
+    devices beyond the batch size left idle, one private context per replica."""
     from terran_amd import facade, runtime
     made = []
     monkeypatch.setattr(runtime, 'get_context', lambda d=None: ('shared', d))
@@ -244,7 +244,7 @@ def test_fanout_shards_contiguously_and_keeps_order(monkeypatch):
             return [(x, ctx) for x in items]
         return rep
     fo = facade._Fanout([0, 1, 0], make)
-    assert made == [(0, ('shared', 0)), (1, ('shared', 1)), (0, ('new', 0))]
+    assert made == [(0, ('new', 0)), (1, ('new', 1)), (0, ('new', 0))]            # every replica owns its context
     out = fo(list(range(8)), list('abcdefgh'), _canvas=(3, 4))
     assert [x for x, _ in out] == list(range(8))                                       # frame order kept
     got = sorted(calls, key=lambda c: c[2][0])
