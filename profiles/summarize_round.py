@@ -38,8 +38,9 @@ def kernel_tables(db_path, prefix):
         w.writerow(['kernel', 'grid_x', 'workgroup_x', 'lds_bytes', 'vgpr', 'agpr', 'sgpr', 'duration_ns'])
         w.writerows(disp)
     conv = [(n, c, t) for n, c, t, _, _ in rows if 'conv_' in n or 'rf_stem' in n]
-    return {'conv_launches': sum(c for _, c, _ in conv), 'conv_total_ms': sum(t for _, _, t in conv) / 1e6,
-            'all_kernels_ms': sum(r[2] for r in rows) / 1e6, 'steps_in_trace': 5}
+    unit = 1e6 if max(r[2] for r in rows) > 1e6 else 1e3            # rocpd's top_kernels view: ns (older) or us
+    return {'conv_launches': sum(c for _, c, _ in conv), 'conv_total_ms': sum(t for _, _, t in conv) / unit,
+            'all_kernels_ms': sum(r[2] for r in rows) / unit, 'steps_in_trace': 5}
 
 
 def pmc_total(db_path, counter):

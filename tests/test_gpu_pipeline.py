@@ -639,3 +639,13 @@ def test_fanout_two_contexts_equal_one_way(states, precision):
     psf.free()
     with pytest.raises(NotImplementedError):
         Detection(merge_method='crop', device=[0, 0], state=states('retinaface'))(lst)
+
+
+def test_arcface_plans_go_by_capacity_bucket(arc):
+    """The face count of a video batch changes on every call: ArcFace plans are carved for a bucketed capacity (8, 32,
+    multiples of 64) and launches cover exactly the crops of the call, so any count gives the rows of the full batch,
+    bit for bit, without re-planning per count."""
+    crops = np.random.default_rng(77).integers(0, 256, (70, 3, 112, 112), dtype=np.uint8)
+    full = arc.embed_crops(crops)
+    for n in (1, 3, 8, 9, 31, 33, 64, 65):
+        assert np.array_equal(arc.embed_crops(crops[:n]), full[:n]), n
