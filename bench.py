@@ -191,7 +191,11 @@ def run(args):
             torch.cuda.set_device(device_index)
             dist.init_process_group(backend='nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', device_index))
-            gather_group = dist.new_group(backend='gloo')            # host-side ordered gather of result objects
+            try:
+                gather_group = dist.new_group(backend='gloo')        # host-side ordered gather of result objects
+            except Exception as e:                                   # no gloo beside RCCL here: gather over RCCL instead
+                print('bench: gloo group unavailable (%s); gathering over the default group' % e, file=sys.stderr)
+                gather_group = None
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
@@ -407,74 +411,70 @@ def run(args):
         k = max(args.steps, int(np.ceil(args.sustain_seconds / per_step)))
         e, _ = timed(k)
         res['sustained'] = {'steps': k, 'seconds': round(e, 3), 'value': fps(e, k), 'ms_per_step': round(e / k * 1e3, 3)}
+        try:
+            ingest_leg(res)
+        except Exception as ex:                                   # the headline must survive a failing secondary leg
+            import traceback
+            traceback.print_exc()
+            res['ingest'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+
+    def ingest_leg(res):
         # -- ingest: frames come from host memory through RawVideoReader (pinned double buffers, own upload stream per
-        #    pipeline), results are gathered in step order on rank 0 inside the timed region
+        #    pipeline), the region's per-step results are gathered in rank order on rank 0 inside the timed region
         k = max(2 * L, min(args.steps, 60))
         gathered = []
         lock = threading.Lock()
 
-        def on_step(dets, feats, poses):
-            item = (dets, feats, poses)
-            if use_dist:
-                item = shard.gather_results([item], dist if gather_group is None else _GroupDist(dist, gather_group))
-            with lock:
-                if item is not None:
-                    gathered.append(item)
-        # gather_object is a collective: with more than one rank the steps must be gathered in the same order
-        # everywhere, so under torchrun each rank gathers from ONE collector thread (pipeline order = step order)
+        def pack_step(dets, feats, poses):
+            """The per-frame results of one step as a few arrays (what travels to rank 0; the dicts can be rebuilt there)."""
+            return (np.array([len(d) for d in dets], np.int32),
+                    np.array([x['bbox'] for d in dets for x in d], np.int32).reshape(-1, 4),
+                    np.array([x['landmarks'] for d in dets for x in d], np.int32).reshape(-1, 5, 2),
+                    np.array([x['score'] for d in dets for x in d], np.float32),
+                    [np.asarray(f) for f in feats],
+                    np.array([len(p) for p in poses], np.int32),
+                    np.array([x['keypoints'] for p in poses for x in p], np.int32).reshape(-1, 18, 3),
+                    np.array([x['score'] for p in poses for x in p], np.float64))
+
+        def on_step(dets, feats, poses):                 # called per finished step (pipelines finish out of order
+            with lock:                                    # relative to each other; every pipeline's own steps are in order)
+                gathered.append(pack_step(dets, feats, poses) if use_dist else (dets, feats, poses))
         readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, L))), W, H,
                                         batch_size=args.batch, device=device_index) for i in range(L)]
+        n_on_rank0 = [0]
+
+        def gather_all():
+            # ONE ordered gather of the region's per-step results on rank 0 (a single collective per region keeps the ranks
+            # in lock step whatever happens inside a step); it is inside the timed region
+            if use_dist:
+                allr = shard.gather_results(list(gathered), dist if gather_group is None else _GroupDist(dist, gather_group))
+                n_on_rank0[0] = len(allr) if allr is not None else 0
+            else:
+                n_on_rank0[0] = len(gathered)
         try:
             run_steps(2 * L, readers=readers)                                        # warm the readers' buffers
-            if use_dist and world > 1:
-                e, _ = timed_ingest_ordered(k, readers, on_step)
-            else:
-                e, _ = timed(k, readers=readers, on_step=on_step)
+            del gathered[:]
+            sync()
+            t0 = time.perf_counter()
+            run_steps(k, readers=readers, on_step=on_step)
+            gather_all()
+            sync()
+            e = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([e], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e = float(t.item())
         finally:
             for r in readers:
                 r.close()
         res['ingest'] = {
             'value': fps(e, k), 'unit': 'frames/s', 'steps': k, 'ms_per_step': round(e / k * 1e3, 3),
             'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
-            'steps_gathered_on_rank0': len(gathered),
+            'steps_gathered_on_rank0': n_on_rank0[0],
             'what': 'same workload, every batch read from a raw rgb24 byte stream in host memory into pinned buffers and '
                     'uploaded by video.RawVideoReader (one reader thread + upload stream per pipeline, overlapped with '
-                    'compute), per-step results gathered in order on rank 0; stream reads are single-thread host memcpys '
+                    'compute), the per-step results of all ranks gathered on rank 0 inside the timed region; stream reads are single-thread host memcpys '
                     '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
-
-    def timed_ingest_ordered(k, readers, on_step):
-        """Multi-rank ingest: steps run as in run_steps but results are handed to the collective gather strictly in
-        step order by one thread (pipelines finish out of order relative to each other)."""
-        slots = {}
-        cv = threading.Condition()
-
-        def make_cb(pi):
-            count = [0]
-
-            def cb(dets, feats, poses):
-                with cv:
-                    slots[pi + L * count[0]] = (dets, feats, poses)
-                    count[0] += 1
-                    cv.notify_all()
-            return cb
-
-        def gatherer():
-            for s in range(k):
-                with cv:
-                    cv.wait_for(lambda: s in slots)
-                    item = slots.pop(s)
-                on_step(*item)
-        sync()
-        t0 = time.perf_counter()
-        g = pool.submit(gatherer)
-        joins = [p.start(len(range(i, k, L)), readers[i], make_cb(i)) for i, p in enumerate(pipes)]
-        outs = [j() for j in joins]
-        g.result()
-        sync()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), outs
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'bf16x3')
     head = run_mode(primary, args.steps, extra_headline)
@@ -561,9 +561,19 @@ def run(args):
         p.free()
     pool.shutdown()
     if rank == 0 and world == 1 and not args.single_mode:
-        result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'])
+        try:
+            result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'])
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            result['per_model'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
+        try:
+            result['cpu_baseline'] = cpu_baseline(frames_host[:args.cpu_frames], F, sd_r, sd_a, sd_p, fallback_lm)
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            result['cpu_baseline'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -11,23 +11,38 @@ _TEMPLATE[:, 0] += 8.0
 _IDENTITY = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
 
 
-def align_matrix(landmarks):
-    """Inverse 2x3 similarity (6 float64, PIL AFFINE convention) taking crop pixels to image
-    coordinates: least-squares similarity landmarks -> template (Umeyama; closed form in 2-D,
-    proper rotations only), inverted.  arcface/wrapper.py:50-61."""
-    p = np.asarray(landmarks).astype(np.float32).astype(np.float64)
+def align_matrices(landmarks):
+    """(n,5,2) landmark sets -> (n,6) inverse 2x3 similarities (float64, PIL AFFINE convention) taking crop pixels to
+    image coordinates: least-squares similarity landmarks -> template (Umeyama; closed form in 2-D, proper rotations
+    only), inverted in closed form.  arcface/wrapper.py:50-61.  One vectorised pass for all faces of a frame batch
+    (element-wise float64 arithmetic in a fixed association order, so a face's matrix does not depend on its batch)."""
+    p = np.asarray(landmarks).astype(np.float32).astype(np.float64).reshape(-1, 5, 2)
     q = _TEMPLATE.astype(np.float64)
-    pm, qm = p.mean(0), q.mean(0)
-    pd, qd = p - pm, q - qm
-    var = (pd * pd).sum() / p.shape[0]
-    a = (pd[:, 0] * qd[:, 0] + pd[:, 1] * qd[:, 1]).sum() / p.shape[0] / var     # s*cos
-    b = (pd[:, 0] * qd[:, 1] - pd[:, 1] * qd[:, 0]).sum() / p.shape[0] / var     # s*sin
-    R = np.array([[a, -b], [b, a]])
-    t = qm - R @ pm
-    T = np.eye(3)
-    T[:2, :2] = R
-    T[:2, 2] = t
-    return np.linalg.inv(T)[:2].reshape(6)
+    px, py = p[:, :, 0], p[:, :, 1]
+    pmx = (((px[:, 0] + px[:, 1]) + px[:, 2]) + px[:, 3] + px[:, 4]) / 5.0
+    pmy = (((py[:, 0] + py[:, 1]) + py[:, 2]) + py[:, 3] + py[:, 4]) / 5.0
+    qm = q.mean(0)
+    qd = q - qm
+    dx, dy = px - pmx[:, None], py - pmy[:, None]
+    var = np.zeros(len(p))
+    a = np.zeros(len(p))
+    b = np.zeros(len(p))
+    for k in range(5):                                             # fixed order over the five points
+        var = var + (dx[:, k] * dx[:, k] + dy[:, k] * dy[:, k])
+        a = a + (dx[:, k] * qd[k, 0] + dy[:, k] * qd[k, 1])        # s*cos (x n var)
+        b = b + (dx[:, k] * qd[k, 1] - dy[:, k] * qd[k, 0])        # s*sin (x n var)
+    a, b = a / var, b / var                                        # the 1/n factors cancel
+    tx = qm[0] - (a * pmx - b * pmy)
+    ty = qm[1] - (b * pmx + a * pmy)
+    # inverse of [[a,-b,tx],[b,a,ty],[0,0,1]]
+    d = a * a + b * b
+    ia, ib = a / d, b / d
+    return np.stack([ia, ib, -(ia * tx + ib * ty), -ib, ia, ib * tx - ia * ty], axis=1)
+
+
+def align_matrix(landmarks):
+    """One face: 6 float64 (see align_matrices)."""
+    return align_matrices(np.asarray(landmarks)[None])[0]
 
 
 class ArcFace:
@@ -69,8 +84,8 @@ class ArcFace:
             counts = [len(f) for f in faces_per_image]
             if sum(counts) == 0:
                 return [np.empty((0, 512)) for _ in counts]
-            idx = [i for i, f in enumerate(faces_per_image) for _ in f]
-            mats = [align_matrix(face['landmarks']) for f in faces_per_image for face in f]
+            idx = np.repeat(np.arange(len(counts)), counts)
+            mats = align_matrices(np.array([face['landmarks'] for f in faces_per_image for face in f]))
             return np.split(self.embed_faces(images, idx, mats), np.cumsum(counts)[:-1], axis=0)
         n_images = len(images)
         if faces_per_image is not None:
@@ -91,7 +106,7 @@ class ArcFace:
                 slot = {i: s for s, i in enumerate(img_ids)}
                 frames = self.ctx.upload(np.stack([np.asarray(images[i]) for i in img_ids]))
                 try:
-                    mats = [align_matrix(face['landmarks']) for _, _, face in items]
+                    mats = align_matrices(np.array([face['landmarks'] for _, _, face in items]))
                     out = self.embed_faces(frames, [slot[i] for i, _, _ in items], mats)
                 finally:
                     frames.free()

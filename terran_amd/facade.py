@@ -198,21 +198,30 @@ class Detection:
             counts, boxes, lmks, scores = self.model.detect_arrays(frames)
         finally:
             frames.free()
-        if not isinstance(scales, list):
-            scales = [scales] * len(counts)
+        if pads is None:
+            # one scale for the whole batch (ndarray / resident frames): un-scale and round every detection at once -- the
+            # same float32 element-wise arithmetic as the reference's per-face code (face/detection/__init__.py:59-84)
+            b = np.around(boxes / scales).astype(np.int32)
+            l = np.around(lmks / scales).astype(np.int32)
+            out, o = [], 0
+            for c in counts:
+                c = int(c)
+                out.append([{'bbox': x, 'landmarks': y, 'score': z}
+                            for x, y, z in zip(b[o:o + c], l[o:o + c], scores[o:o + c])])
+                o += c
+            return out[0] if expanded else out
         # un-pad and un-scale one image at a time (same element-wise arithmetic and dtypes as the
         # reference's per-face code, face/detection/__init__.py:59-84,141-176), then hand out row views
         out, o = [], 0
         for i, c in enumerate(counts):
             c = int(c)
             b, l = boxes[o:o + c], lmks[o:o + c]
-            if pads is not None:
-                top, left = pads[i][0][0], pads[i][1][0]
-                b = b - np.array([left, top, left, top], np.float32)            # float32 - int stays float32
-                l = l - np.array([left, top]).reshape(1, 1, 2)                  # int64 array: promotes to float64
+            top, left = pads[i][0][0], pads[i][1][0]
+            b = b - np.array([left, top, left, top], np.float32)            # float32 - int stays float32
+            l = l - np.array([left, top]).reshape(1, 1, 2)                  # int64 array: promotes to float64
             b = np.around(b / scales[i]).astype(np.int32)
             l = np.around(l / scales[i]).astype(np.int32)
-            out.append([{'bbox': b[k], 'landmarks': l[k], 'score': scores[o + k]} for k in range(c)])
+            out.append([{'bbox': x, 'landmarks': y, 'score': z} for x, y, z in zip(b, l, scores[o:o + c])])
             o += c
         return out[0] if expanded else out
 

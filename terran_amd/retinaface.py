@@ -44,8 +44,10 @@ class RetinaFace:
         counts, boxes, lmks, scores = self.detect_arrays(frames, threshold)
         out, o = [], 0
         for c in counts:
-            out.append([{'bbox': boxes[i], 'landmarks': lmks[i], 'score': scores[i]} for i in range(o, o + int(c))])
-            o += int(c)
+            c = int(c)
+            out.append([{'bbox': b, 'landmarks': l, 'score': s}
+                        for b, l, s in zip(boxes[o:o + c], lmks[o:o + c], scores[o:o + c])])
+            o += c
         return out
 
     def call(self, images, threshold=0.5):
