@@ -607,7 +607,7 @@ C3_GFLOP_PER_CROP, C4_GFLOP_PER_IMAGE, C2_GFLOP_PER_IMAGE = 24.1792, 484.634, 1.
 
 
 def per_model(ctx, precisions, reps=8):
-    from terran_amd import arcface, openpose, retinaface, synth, weights
+    from terran_amd import arcface, openpose, retinaface, runtime, synth, weights
 
     def timed(fn, reps, warm=2):
         for _ in range(warm):
@@ -646,6 +646,37 @@ def per_model(ctx, precisions, reps=8):
                          'algorithmic_bytes_per_image': C2_BYTES_PER_IMAGE,
                          'note': 'SURVEY.md 8(d) unfused bf16 activation bytes (56.3 MB/img + 0.84 MB weights per batch) / '
                                  'summed kernel time of the whole call (achieved) and / wall time per batch (achieved_wall)'}}
+        # The wrapper call spends ~40 % of its wall time building the reference's return type (one dict of three
+        # ndarray views per detection, ~4.9 k of them per batch here) under the GIL.  `packed`: the same C-ABI call
+        # returning the packed (counts, boxes, landmarks, scores) arrays (RetinaFace.detect_arrays) -- from one host
+        # thread, and from two threads on two contexts (what the pipelined headline does with every model).
+        row = rows['C2 RetinaFace 32x640x640 ' + prec]
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            dtp, _ = timed(lambda: det.detect_arrays(c2), reps)
+            row['images_per_s_packed'] = round(32 / dtp, 1)
+            row['detections_per_batch'] = int(det.detect_arrays(c2)[0].sum())
+            ctx_b = runtime.new_context(ctx.device_id)
+            det_b = retinaface.RetinaFace(device=ctx.device_id, state=sd_r, precision=prec, ctx=ctx_b)
+            c2_b = ctx_b.upload(synth.frames(1, 32, 640, 640))
+            pairs = [(det, c2), (det_b, c2_b)]
+
+            def loop(k, n):
+                d, f = pairs[k]
+                for _ in range(n):
+                    d.detect_arrays(f)
+            with ThreadPoolExecutor(2) as ex:
+                list(ex.map(lambda k: loop(k, 2), range(2)))
+                t0 = time.perf_counter()
+                list(ex.map(lambda k: loop(k, 2 * reps), range(2)))
+                dt2 = (time.perf_counter() - t0) / (4 * reps)
+            row['images_per_s_packed_two_in_flight'] = round(32 / dt2, 1)
+            row['roofline']['achieved_wall_packed'] = round(bytes_batch / dtp / 1e9, 1)
+            row['roofline']['achieved_wall_packed_two_in_flight'] = round(bytes_batch / dt2 / 1e9, 1)
+            c2_b.free()
+            det_b.model.free()
+        except Exception as ex:                      # secondary figures: never take the leg down
+            row['images_per_s_packed'] = 'error: %s' % ex
         det.model.free()
         arc = arcface.ArcFace(device=ctx.device_id, state=sd_a, precision=prec, ctx=ctx)
         dt, prof = timed(lambda: arc.embed_crops(c3), max(2, reps // 2))

@@ -136,7 +136,11 @@ int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int 
 /* ---- OpenPose.call (openpose/wrapper.py:182-485) ---------------------------------------- */
 /* frames: uint8 RGB ALREADY at network resolution (the wrapper's resize is ta_frames_resize);
  * scale = short_side / min(H_orig, W_orig) maps keypoints back ((coord/scale) truncated).
- * keypoints: (M,18,3) int32 (x, y, present); scores: (M,) float64; counts[i] humans of image i. */
+ * keypoints: (M,18,3) int32 (x, y, present); scores: (M,) float64; counts[i] humans of image i.
+ * The grouping kernels hold at most 1024 peaks per part, 8192 candidate pairs per limb and 192 people under assembly
+ * per image (the reference has no such limits; they are ~50x anything a real frame produces): an image over one of
+ * them does not fail the call -- its count is -1 and it contributes no rows, the other images' results stand, and
+ * ta_last_error names the condition. */
 int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capacity,
                     int32_t* counts, int32_t* keypoints, double* scores, int32_t* required);
 /* Grouping only (x8 bicubic, peaks, PAF scoring, greedy matching, assembly) on host maps at

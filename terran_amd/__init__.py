@@ -8,7 +8,7 @@ mirror `terran.face_detection / extract_features / pose_estimation`
 from .facade import Detection, Recognition, Estimation          # noqa: F401
 from .retinaface import RetinaFace                                # noqa: F401
 from .arcface import ArcFace                                      # noqa: F401
-from .openpose import OpenPose                                    # noqa: F401
+from .openpose import OpenPose, PoseOverflow                      # noqa: F401
 
 face_detection = Detection(lazy=True)
 extract_features = Recognition(lazy=True)

@@ -151,7 +151,7 @@ struct op_work {
   int* conn_cnt;       // [N][19]   (-1 = limb missing)
   int* conn_ij;        // [N][19][OP_MAXP][2]
   float* conn_sc;      // [N][19][OP_MAXP]
-  int* overflow;       // [1] sticky flag
+  int* overflow;       // [N] image i ran into one of the caps above (its result is dropped, the others stand)
   double scale;
   int* out_cnt;        // [N]
   int* out_kp;         // [N][OP_MAXH][18][3]
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
   __syncthreads();
   int C = s_count;
   if (C > OP_MAXP) {
-    if (tid == 0) atomicExch(w.overflow, 1);
+    if (tid == 0) atomicExch(w.overflow + img, 1);
     C = OP_MAXP;
   }
   int P = 1;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
   }
   int C = s_base;
   if (C > OP_MAXC) {
-    if (tid == 0) atomicExch(w.overflow, 1);
+    if (tid == 0) atomicExch(w.overflow + img, 1);
     C = OP_MAXC;
   }
   int P = 1;
@@ -505,7 +505,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
       __syncthreads();
     }
   }
-  if (over && lane == 0) atomicExch(w.overflow, 1);
+  const bool truncated = w.overflow[img] != 0;      // peaks / limbs of this image were cut short by the kernels before
+  if (over && lane == 0) atomicExch(w.overflow + img, 1);
+  over = over || truncated;
   // filter + keypoints (wrapper.py:470-483, 37-90)
   int kept = 0;
   for (int h = 0; h < nh; ++h) {
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
     if (lane == 0) w.out_sc[(size_t)img * OP_MAXH + kept] = tot / cnt;
     ++kept;
   }
-  if (lane == 0) w.out_cnt[img] = kept;
+  if (lane == 0) w.out_cnt[img] = over ? 0 : kept;   // a truncated image reports nothing (flagged in w.overflow)
 }
 
 __global__ __launch_bounds__(256) void op_gather_kernel(const op_work w, int* o_kp, double* o_sc) {
@@ -610,20 +612,18 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
     off += rup256(b);
     return o;
   };
-  const size_t o_wph = carve(128);
   const size_t o_pcnt = carve((size_t)N * 18 * 4), o_pyx = carve((size_t)N * 18 * OP_MAXP * 8), o_psc = carve((size_t)N * 18 * OP_MAXP * 4);
   const size_t o_ccnt = carve((size_t)N * 19 * 4), o_cij = carve((size_t)N * 19 * OP_MAXP * 8), o_csc = carve((size_t)N * 19 * OP_MAXP * 4);
-  const size_t o_ovf = carve(256), o_ocnt = carve((size_t)N * 4), o_okp = carve((size_t)N * OP_MAXH * 54 * 4), o_osc = carve((size_t)N * OP_MAXH * 8);
+  const size_t o_ovf = carve((size_t)N * 4), o_ocnt = carve((size_t)N * 4), o_okp = carve((size_t)N * OP_MAXH * 54 * 4), o_osc = carve((size_t)N * OP_MAXH * 8);
   const size_t cap = capacity > 0 ? (size_t)capacity : 0;
   const size_t o_gkp = carve(cap * 54 * 4), o_gsc = carve(cap * 8);
   char* scr = nullptr;
   TA_TRY(ta_scratch(ctx, off, (void**)&scr));
-  {
-    void* pin = nullptr;
-    TA_TRY(ta_pinned(ctx, 128, &pin));
-    phase_weights((float*)pin);
-    TA_HIP(ctx, hipMemcpyAsync(scr + o_wph, pin, 128, hipMemcpyHostToDevice, ctx->stream));
-    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the pinned block is reused by later calls
+  if (!ctx->pose_wphase) {                                // constants: uploaded once per context, no per-call copy / sync
+    float wp[32];
+    phase_weights(wp);
+    TA_HIP(ctx, hipMalloc((void**)&ctx->pose_wphase, sizeof(wp)));
+    TA_HIP(ctx, hipMemcpy(ctx->pose_wphase, wp, sizeof(wp), hipMemcpyHostToDevice));
   }
   const size_t map_bytes = (size_t)m.h * m.w * 4;
   const size_t lds_peaks = ((map_bytes + 15) & ~(size_t)15) + 128 + (size_t)OP_MAXP * 8;
@@ -633,7 +633,7 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   op_work w;
   memset(&w, 0, sizeof(w));
   w.m = m;
-  w.wphase = (const float*)(scr + o_wph);
+  w.wphase = ctx->pose_wphase;
   w.N = N;
   w.H8 = H8;
   w.W8 = W8;
@@ -648,7 +648,7 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   w.out_cnt = (int*)(scr + o_ocnt);
   w.out_kp = (int*)(scr + o_okp);
   w.out_sc = (double*)(scr + o_osc);
-  TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, 4, ctx->stream));
+  TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, (size_t)N * 4, ctx->stream));
   ctx->pose_dbg.n = N;
   ctx->pose_dbg.maxp = OP_MAXP;
   ctx->pose_dbg.peak_cnt = w.peak_cnt;
@@ -675,27 +675,40 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
     hipLaunchKernelGGL(assemble_kernel, dim3(N), dim3(64), 0, ctx->stream, w);
     TA_HIP(ctx, hipGetLastError());
   }
-  int ovf = 0;
+  std::vector<int> ovf(N);
   std::vector<int> stat((size_t)N * 37);           // peaks per (image, part) and connections per (image, limb): statistics only
   TA_HIP(ctx, hipMemcpyAsync(counts, w.out_cnt, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-  TA_HIP(ctx, hipMemcpyAsync(&ovf, w.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(ovf.data(), w.overflow, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(stat.data(), w.peak_cnt, (size_t)N * 18 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(stat.data() + (size_t)N * 18, w.conn_cnt, (size_t)N * 19 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->pose_peaks = ctx->pose_connections = 0;
   for (size_t i = 0; i < (size_t)N * 18; ++i) ctx->pose_peaks += stat[i];
   for (size_t i = (size_t)N * 18; i < stat.size(); ++i) ctx->pose_connections += stat[i] > 0 ? stat[i] : 0;   // -1 = limb missing
-  if (ovf) return ta_fail(ctx, TA_E_OVERFLOW, "openpose: more than %d peaks per part, %d candidate pairs per limb or %d humans in one image", OP_MAXP, OP_MAXC, OP_MAXH);
   long long total = 0;
-  for (int i = 0; i < N; ++i) total += counts[i];
+  for (int i = 0; i < N; ++i) total += counts[i];          // 0 for an image over a cap
   if (required) *required = (int32_t)total;
   if (total > capacity) return ta_fail(ctx, TA_E_CAPACITY, "openpose: %lld humans, capacity %d", total, capacity);
-  if (total == 0) return TA_OK;
-  hipLaunchKernelGGL(op_gather_kernel, dim3(N), dim3(256), 0, ctx->stream, w, (int*)(scr + o_gkp), (double*)(scr + o_gsc));
-  TA_HIP(ctx, hipGetLastError());
-  TA_HIP(ctx, hipMemcpyAsync(keypoints, scr + o_gkp, (size_t)total * 54 * 4, hipMemcpyDeviceToHost, ctx->stream));
-  TA_HIP(ctx, hipMemcpyAsync(scores, scr + o_gsc, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (total > 0) {
+    hipLaunchKernelGGL(op_gather_kernel, dim3(N), dim3(256), 0, ctx->stream, w, (int*)(scr + o_gkp), (double*)(scr + o_gsc));
+    TA_HIP(ctx, hipGetLastError());
+    TA_HIP(ctx, hipMemcpyAsync(keypoints, scr + o_gkp, (size_t)total * 54 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipMemcpyAsync(scores, scr + o_gsc, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // an image over a cap does not take the batch down: its count comes back as -1, everything else stands
+  int n_over = 0;
+  for (int i = 0; i < N; ++i)
+    if (ovf[i]) {
+      counts[i] = -1;
+      ++n_over;
+    }
+  if (n_over) {
+    char msg[200];
+    snprintf(msg, sizeof(msg), "openpose: %d image(s) with more than %d peaks per part, %d candidate pairs per limb or %d humans (count -1)",
+             n_over, OP_MAXP, OP_MAXC, OP_MAXH);
+    ctx->err = msg;
+  }
   return TA_OK;
 }
 

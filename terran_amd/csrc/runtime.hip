@@ -35,6 +35,7 @@ int ta_pinned(ta_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->pinned_bytes) {
     TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pose_wphase) (void)hipFree(ctx->pose_wphase);
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
     size_t want = bytes + bytes / 4 + (1 << 16);

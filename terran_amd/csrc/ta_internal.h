@@ -104,6 +104,7 @@ struct ta_ctx {
   std::vector<std::pair<size_t, void*>> frame_cache;
   size_t frame_cache_bytes = 0;
   int64_t pose_peaks = 0, pose_connections = 0;    // statistics of the last OpenPose grouping on this context
+  float* pose_wphase = nullptr;                    // x8 bicubic phase weights on the device (uploaded once per context)
   // where the last grouping left its per-stage results in the scratch block (ta_openpose_debug_read); n = 0: none
   struct {
     int n = 0, maxp = 0;

@@ -124,6 +124,9 @@ class Context:
         if rc != OK:
             raise TerranAmdError(rc, self.lib.ta_last_error(self.h).decode(errors='replace'))
 
+    def last_error(self):
+        return self.lib.ta_last_error(self.h).decode(errors='replace')
+
     def sync(self):
         self.check(self.lib.ta_ctx_sync(self.h))
 

@@ -6,9 +6,23 @@ import numpy as np
 from . import lib, pack, runtime
 
 
+class PoseOverflow(RuntimeError):
+    """An image went over a grouping cap of the device kernels (1024 peaks per part / 8192 candidate pairs per limb /
+    192 people; the reference has no such limits).  The other images of the batch are not lost: `results` is the full
+    per-image list with `None` at the positions in `images`."""
+
+    def __init__(self, message, results, images):
+        super().__init__(message)
+        self.results = results
+        self.images = images
+
+
 def _unpack(counts, kp, sc):
     out, o = [], 0
     for c in counts:
+        if c < 0:                                   # over a cap: no rows for this image
+            out.append(None)
+            continue
         out.append([{'keypoints': kp[i].copy(), 'score': np.float64(sc[i])} for i in range(o, o + int(c))])
         o += int(c)
     return out
@@ -26,7 +40,11 @@ def _run(ctx, fn, n):
             cap = int(req.value)
             continue
         ctx.check(rc)
-        return _unpack(counts[:n], kp, sc)
+        out = _unpack(counts[:n], kp, sc)
+        over = [i for i, r in enumerate(out) if r is None]
+        if over:
+            raise PoseOverflow(ctx.last_error() + '; images %s' % over, out, over)
+        return out
 
 
 class OpenPose:
