@@ -121,7 +121,7 @@ class LoopStream(io.RawIOBase):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=120)
+    ap.add_argument('--steps', type=int, default=144)       # >= 2 s timed region at ~15 ms per step
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (examples/video.py:12)')
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
