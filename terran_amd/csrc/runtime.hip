@@ -35,7 +35,6 @@ int ta_pinned(ta_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->pinned_bytes) {
     TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  if (ctx->pose_wphase) (void)hipFree(ctx->pose_wphase);
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
     size_t want = bytes + bytes / 4 + (1 << 16);
@@ -129,6 +128,7 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pose_wphase) (void)hipFree(ctx->pose_wphase);
   for (auto& e : ctx->frame_cache) (void)hipFree(e.second);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
