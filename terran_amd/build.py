@@ -15,6 +15,21 @@ SOURCES = ['runtime.hip', 'conv_igemm.hip', 'layers.hip', 'net.hip', 'retinaface
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
+STAMP = LIB + '.stamp'
+
+
+def source_hash():
+    """sha256 over every kernel source, header and the compile flags: what the built .so must correspond to."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'terran_amd.h'))
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -51,6 +66,8 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stdout.decode(errors='replace'))
+    with open(STAMP, 'w') as fh:                 # lib.load() refuses a binary that does not match the sources beside it
+        fh.write(source_hash() + '\n')
     return LIB
 
 

@@ -87,6 +87,16 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise TerranAmdError(E_DEVICE, 'libterran_amd.so not built (run `python -m terran_amd.build`); '
                                            'there is no CPU fallback')
+        # the .so travels prebuilt to the GPU box: it must be the build of the sources that travel beside it
+        from . import build as _build
+        try:
+            with open(_build.STAMP) as fh:
+                stamp = fh.read().strip()
+        except OSError:
+            stamp = None
+        if stamp != _build.source_hash() and not os.environ.get('TA_ALLOW_STALE_LIB'):
+            raise TerranAmdError(E_DEVICE, 'libterran_amd.so was not built from the sources in terran_amd/csrc '
+                                           '(run `python -m terran_amd.build`)')
         lib = C.CDLL(LIB_PATH)
         missing = []
         for name, (res, args) in SIGNATURES.items():

@@ -29,6 +29,18 @@ def test_abi_exports_every_declared_symbol():
     assert b'terran_amd' in so.ta_version()
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """The .so travels prebuilt to the GPU box: loading one that was not built from the sources beside it must fail
+    loudly (no silent run of an old kernel), and there is no CPU fallback behind it."""
+    from terran_amd import build, lib
+    build.build()
+    assert open(build.STAMP).read().strip() == build.source_hash()
+    monkeypatch.setattr(lib, '_lib', None)
+    monkeypatch.setattr(build, 'source_hash', lambda: 'edited-after-the-build')
+    with pytest.raises(lib.TerranAmdError, match='not built from the sources'):
+        lib.load()
+
+
 def test_no_gpu_fails_loudly():
     """No CPU fallback: without a gfx950 device the product path raises (unless a GPU is present)."""
     from terran_amd import lib
