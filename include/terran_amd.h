@@ -36,7 +36,7 @@ extern "C" {
 #define TA_E_INVALID (-1)   /* bad argument / malformed model blob            */
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
-#define TA_E_OVERFLOW (-4)  /* an internal per-image working limit was hit    */
+#define TA_E_OVERFLOW (-4)  /* a working limit of the whole call was hit (per-image pose limits: see ta_openpose_run) */
 
 #define TA_MODEL_RETINAFACE 1
 #define TA_MODEL_ARCFACE 2
