@@ -375,6 +375,10 @@ struct ta_k_walk {
     kh = p.k_h;
     pix_bytes = p.in_pix * 4;
     row_bytes = p.in_row * 4;
+    if (s0 == 0) {                               // every launch but the K-split ones starts at slab 0: no division
+      cb = kx = ky = b_off = a_slab = 0;
+      return;
+    }
     const int taps = kw * kh;
     cb = s0 / taps;
     const int tap = s0 - cb * taps;
@@ -793,6 +797,17 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
 }
 
+// t / d for a launch-uniform divisor whose float32 reciprocal the launcher supplied: one multiply and a +-1 fix-up
+// (exact for 0 <= t < 2^24, which the launcher checks: fast_div)
+__device__ __forceinline__ int ta_div_r(int t, int d, float rd, int fast) {
+  if (!fast) return t / d;
+  int q = (int)((float)t * rd);
+  const int r = t - q * d;
+  if (r < 0) --q;
+  else if (r >= d) ++q;
+  return q;
+}
+
 // (img, y, x) of the pixels pt0 + d of a tile, without a full integer division per lane: the tile's first pixel is
 // decomposed once (wave-uniform), every other pixel is d < 65536 further in raster order, so its carries are small
 // quotients that an f32 multiply by the reciprocal gets right to +-1 (fixed up exactly).
@@ -800,12 +815,21 @@ struct ta_pixel_walk {
   int img0, y0, x0, Wo, Ho;
   float rWo, rHo;
   __device__ __forceinline__ ta_pixel_walk(const ta_conv_launch& p, int pt0, int HoWo) {
+    Wo = p.Wo;
+    Ho = p.Ho;
+    if (p.fast_div) {                            // split-role launches: reciprocals from the launcher
+      img0 = ta_div_r(pt0, HoWo, p.r_HoWo, 1);
+      const int rem = pt0 - img0 * HoWo;
+      y0 = ta_div_r(rem, Wo, p.r_Wo, 1);
+      x0 = rem - y0 * Wo;
+      rWo = p.r_Wo;
+      rHo = p.r_Ho;
+      return;
+    }
     img0 = pt0 / HoWo;
     const int rem = pt0 - img0 * HoWo;
     y0 = rem / p.Wo;
     x0 = rem - y0 * p.Wo;
-    Wo = p.Wo;
-    Ho = p.Ho;
     rWo = 1.0f / (float)p.Wo;
     rHo = 1.0f / (float)p.Ho;
   }
@@ -1066,19 +1090,24 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
   if (wave == 0) TA_STAMP(0);                       // kernel entry (consumer 0)
   if (wave == NC) TA_STAMP(8);                      // kernel entry (producer 0)
 
-  const int n_ct = p.coutp / BN;
+  // set-up without integer divisions (launch-uniform divisors come with their reciprocals; K ranges only when K-split)
+  const int n_ct = p.coutp / BN;                                 // BN, BM: powers of two
   const int n_pt = (p.M + BM - 1) / BM;
   const int tile_blocks = (((n_pt + 7) >> 3) * n_ct) << 3;      // blocks per K range
-  const int ks = blockIdx.x / tile_blocks;                       // K range of this workgroup (0 unless K-split)
+  const int ks = p.k_split > 1 ? ta_div_r(blockIdx.x, tile_blocks, p.r_tile_blocks, p.fast_div) : 0;   // K range of this workgroup
   const int bid = blockIdx.x - ks * tile_blocks;
   const int grp = bid >> 3, xcd = bid & 7;
-  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  const int gq = ta_div_r(grp, n_ct, p.r_nct, p.fast_div);
+  const int pt = ta_xcd_tile(n_pt, xcd, gq);
   if (pt < 0) return;
-  const int ct0 = (grp % n_ct) * BN;
+  const int ct0 = (grp - gq * n_ct) * BN;
   const int pt0 = pt * BM;
   const int HoWo = p.Ho * p.Wo;
-  const int s_begin = (int)(((long long)ks * p.n_slabs) / p.k_split);
-  const int S = (int)(((long long)(ks + 1) * p.n_slabs) / p.k_split) - s_begin;
+  int s_begin = 0, S = p.n_slabs;
+  if (p.k_split > 1) {
+    s_begin = (int)(((long long)ks * p.n_slabs) / p.k_split);
+    S = (int)(((long long)(ks + 1) * p.n_slabs) / p.k_split) - s_begin;
+  }
   // LDS-staged, line-coalesced epilogue whenever every channel slice involved is 8-aligned (always when K-split:
   // the raw sums go to the workspace)
   const bool lds_epilogue = p.k_split > 1 || (((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0);
@@ -1275,9 +1304,12 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
   if (lds_epilogue) {
     __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: the ring can be reused
     asm volatile("" ::: "memory");
+    if (wave == 0) TA_STAMP(5);                     // consumer: past E0
     conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
+    if (wave == 0) TA_STAMP(6);                     // consumer: accumulators parked (LDS writes issued)
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
+    if (wave == 0) TA_STAMP(7);                     // consumer: past E1
     conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
@@ -1323,7 +1355,16 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm_split<CM, CN, NP, PREC, STAGES>;
   TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
-  hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, p);
+  ta_conv_launch q = p;
+  const long long grid = (long long)groups * 8 * p.k_split;
+  q.r_nct = 1.0f / (float)n_ct;
+  q.r_tile_blocks = 1.0f / (float)(groups * 8);
+  q.r_Wo = 1.0f / (float)p.Wo;
+  q.r_Ho = 1.0f / (float)p.Ho;
+  q.r_HoWo = 1.0f / (float)(p.Ho * p.Wo);
+  static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
+  q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, q);
   TA_HIP(ctx, hipGetLastError());
   if (p.k_split > 1) {
     const int total = p.M * (p.cout >> 2);

@@ -228,6 +228,10 @@ struct ta_conv_launch {
   // (t >> 1 & 1, t & 1) of 2x2 window t >> 2, windows in raster order over the POOLED map (Ho x Wo here are the pooled
   // sizes, M = 4 N Ho Wo) -- and the epilogue stores the max of every window instead of the four pixels
   int pool;
+  // filled by the launcher of the split-role kernel: reciprocals of the launch-uniform divisors, so that a workgroup's
+  // set-up needs no integer division (each one is a ~300-cycle dependent instruction chain in front of the first DMA)
+  float r_nct, r_tile_blocks, r_Wo, r_Ho, r_HoWo;
+  int fast_div;                                // 1: every dividend of the set-up is < 2^24 (exact in float32)
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
 };
