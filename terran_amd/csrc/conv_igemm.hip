@@ -1062,6 +1062,147 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   }
 }
 
+// ---- the same phase 2, specialised at compile time for the three epilogues that carry the bf16 workloads (launcher
+// flag fast_drain: split-format tensors addressed with 32-bit byte offsets, every lane's 8 channels inside cout, no
+// pool, no K-split).  The generic drain above spends ~19 lane-instructions per output element on run-time flags and
+// 64-bit addressing and is VALU-issue-bound (tools/conv_trace.py); this one is ~2x leaner.  Same arithmetic, same
+// order, same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8]) {
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2v h = __builtin_convertvector((f32x2){x[2 * i], x[2 * i + 1]}, bf16x2v);
+    hw[i] = __builtin_bit_cast(unsigned, h);
+    const f32x2 r = {x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u)};
+    lw[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
+  }
+  *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+template <int BN, int BM, int NT, int ACT, bool RES, bool POOL = false>     // RES: + shortcut, and the second (affine) output; POOL: fused 2x2 max-pool
+__device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
+  constexpr int NCH = BN / 4;
+  constexpr int G = BN / 8;
+  constexpr int RPI = NT / G;
+  const int k8 = tid % G, r0 = tid / G;
+  const int co = ct0 + 8 * k8;
+  if (co >= p.cout) return;                        // cout % 8 == 0: a lane is inside or outside with all 8 channels
+  float bias[8], sl[8], sc[8], sh[8];
+  *(f32x4*)bias = *(const f32x4*)(p.bias + co);
+  *(f32x4*)(bias + 4) = *(const f32x4*)(p.bias + co + 4);
+  if (ACT == TA_ACT_PRELU) {
+    *(f32x4*)sl = *(const f32x4*)(p.prelu + co);
+    *(f32x4*)(sl + 4) = *(const f32x4*)(p.prelu + co + 4);
+  }
+  if (RES) {
+    *(f32x4*)sc = *(const f32x4*)(p.scale2 + co);
+    *(f32x4*)(sc + 4) = *(const f32x4*)(p.scale2 + co + 4);
+    *(f32x4*)sh = *(const f32x4*)(p.shift2 + co);
+    *(f32x4*)(sh + 4) = *(const f32x4*)(p.shift2 + co + 4);
+  }
+  auto chan = [](int ch) { return (unsigned)(((ch >> 5) << 7) + ((ch & 31) << 1)); };
+  char* const ob = (char*)p.out + chan(p.out_ch + co);
+  const char* const rb = RES ? (const char*)p.res + chan(p.res_ch + co) : nullptr;
+  char* const o2b = RES ? (char*)p.out2 + chan(p.o2_ch + co) : nullptr;
+  // POOL: rows 4 w .. 4 w + 3 of the staged tile are the pixels of window w (lanes G and 2 G apart hold the same 8
+  // channels of a window's other rows); coordinates below are those of the POOLED map and a pass advances STEP of its pixels
+  static_assert(!POOL || (4 * G <= 64 && (RPI & 3) == 0), "a window's four rows live in one wave");
+  constexpr int STEP = POOL ? RPI / 4 : RPI;
+  int img, y, x;
+  ta_pixel_walk(p, POOL ? pt0 >> 2 : pt0, HoWo).at(POOL ? r0 >> 2 : r0, img, y, x);
+  int pix = pt0 + r0;
+  // a pass is STEP pixels further in raster order: (dy rows, dx columns) with at most one carry each when dy < Ho
+  const int dy = ta_div_r(STEP, p.Wo, p.r_Wo, 1), dx = STEP - dy * p.Wo;
+  const bool one_carry = dy < p.Ho;
+#pragma unroll 2
+  for (int row = r0; row < BM; row += RPI, pix += RPI) {
+    if (pix >= p.M) break;
+    const int sw = row & (NCH - 1);
+    float v[8];
+    *(f32x4*)v = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
+    *(f32x4*)(v + 4) = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+    unsigned rh[4], rl[4];
+    if (RES) {
+      const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
+      const char* rs = rb + 4u * (unsigned)(img * p.res_img + ry * p.res_row + rx * p.res_pix + p.res_off0);
+      *(uint4*)rh = *(const uint4*)rs;
+      *(uint4*)rl = *(const uint4*)(rs + 64);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] += bias[e];
+      if (ACT == TA_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
+    }
+    if (RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] += __uint_as_float(rh[i] << 16) + __uint_as_float(rl[i] << 16);
+        v[2 * i + 1] += __uint_as_float(rh[i] & 0xFFFF0000u) + __uint_as_float(rl[i] & 0xFFFF0000u);
+      }
+    }
+    if (POOL) {
+#pragma unroll
+      for (int m = G; m <= 2 * G; m <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], __shfl_xor(v[e], m));
+    }
+    if (!POOL || (row & 3) == 0)
+      ta_split_store8(ob + 4u * (unsigned)(img * p.out_img + y * p.out_row + x * p.out_pix + p.out_off0), v);
+    if (RES) {
+      float z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = v[e] * sc[e] + sh[e];
+      ta_split_store8(o2b + 4u * (unsigned)(img * p.o2_img + y * p.o2_row + x * p.o2_pix + p.o2_off0), z);
+    }
+    if (one_carry) {                                 // branch-free
+      x += dx;
+      const int cx = x >= p.Wo ? 1 : 0;
+      x -= cx ? p.Wo : 0;
+      y += dy + cx;
+      const int cy = y >= p.Ho ? 1 : 0;
+      y -= cy ? p.Ho : 0;
+      img += cy;
+    } else {
+      x += STEP;
+      while (x >= p.Wo) {
+        x -= p.Wo;
+        if (++y == p.Ho) {
+          y = 0;
+          ++img;
+        }
+      }
+    }
+  }
+}
+// picks the lean drain when the launch qualifies; false = run the generic one
+template <int BN, int BM, int NT>
+__device__ __forceinline__ bool conv_drain_dispatch(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
+  if (!p.fast_drain) return false;
+  if (p.pool) {
+    if constexpr (4 * (BN / 8) <= 64 && ((NT / (BN / 8)) & 3) == 0) {
+      if (p.act == TA_ACT_RELU && !p.res && !p.out2) {
+        conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false, true>(p, lds, ct0, pt0, tid, HoWo);
+        return true;
+      }
+    }
+    return false;
+  }
+  if (!p.res && !p.out2) {
+    if (p.act == TA_ACT_RELU) conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false>(p, lds, ct0, pt0, tid, HoWo);
+    else if (p.act == TA_ACT_PRELU) conv_drain_fast<BN, BM, NT, TA_ACT_PRELU, false>(p, lds, ct0, pt0, tid, HoWo);
+    else conv_drain_fast<BN, BM, NT, TA_ACT_NONE, false>(p, lds, ct0, pt0, tid, HoWo);
+    return true;
+  }
+  if (p.res && p.out2 && p.act == TA_ACT_NONE) {
+    conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true>(p, lds, ct0, pt0, tid, HoWo);
+    return true;
+  }
+  return false;
+}
+
 // ---- split-role kernel (f32 mode, or bf16 modes on pre-split activations; 128 x 128 or 64 x 256 tiles) --
 // Measured with tools/probe/*: the global -> LDS DMA path sustains at most ~34 B/clk/CU however many slabs are in
 // flight (24 with only 4 issuing waves), and MFMA issue is NOT slowed by DMA waves on the same SIMD -- but a wave
@@ -1186,7 +1327,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       __builtin_amdgcn_s_barrier();                 // E0
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
-      conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
+      bool done = false;
+      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo);
+      if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
   }
@@ -1310,7 +1453,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(7);                     // consumer: past E1
-    conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
+    bool done = false;
+    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo);
+    if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
   }
@@ -1362,6 +1507,17 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
   q.r_Wo = 1.0f / (float)p.Wo;
   q.r_Ho = 1.0f / (float)p.Ho;
   q.r_HoWo = 1.0f / (float)(p.Ho * p.Wo);
+  {
+    // lean epilogue: split-format tensors whose byte offsets fit 32 bits, channel slices on 8-channel boundaries
+    static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;      // tools: A/B
+    const long long n_img = p.Ho * p.Wo > 0 ? ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo) : 0;
+    auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
+    bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == TA_FMT_SPLIT &&
+              (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
+    if (p.res) ok = ok && p.res_fmt == TA_FMT_SPLIT && fits(p.res_img, p.res_off0);
+    if (p.out2) ok = ok && p.o2_fmt == TA_FMT_SPLIT && fits(p.o2_img, p.o2_off0);
+    q.fast_drain = ok ? 1 : 0;
+  }
   static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
   q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, q);
