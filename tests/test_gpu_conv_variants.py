@@ -46,6 +46,12 @@ LAYERS = {
     'vgg3x3_64_pool_c5': dict(n=8, h=184, w=327, c1=64, cout=64, k=3, act=1, pool=True),
     'vgg3x3_128_pool_c5': dict(n=8, h=92, w=163, c1=128, cout=128, k=3, act=1, pool=True),
     'vgg3x3_256_pool_c5': dict(n=32, h=46, w=81, c1=256, cout=256, k=3, act=1, pool=True),
+    # small / ragged shapes through the specialised epilogues (tile tails, maps narrower than a drain pass, tiny pooled maps)
+    'small_pool': dict(n=3, h=7, w=10, c1=64, cout=64, k=3, act=1, pool=True),
+    'small_pool_128': dict(n=5, h=9, w=5, c1=128, cout=128, k=3, act=1, pool=True),
+    'small_res_out2': dict(n=3, h=5, w=3, c1=128, cout=128, k=3, res=True, out2=True),
+    'small_prelu_256': dict(n=2, h=3, w=2, c1=256, cout=256, k=3, act=2),
+    'small_plain_1x1': dict(n=1, h=1, w=1, c1=256, cout=128, k=1),
     # OpenPose stage output conv: 1x1 128 -> 38 into a channel slice of the 192-channel concat tensor
     'pose1x1_to_slice': dict(n=16, h=46, w=82, c1=128, cout=38, k=1, out_total=192, out_off=128, cout_p=40),
 }
@@ -72,6 +78,9 @@ CASES = [
     ('vgg3x3_128_pool_c5', 'split_2x2', False), ('vgg3x3_128_pool_c5', 'split_2x4', False), ('vgg3x3_128_pool_c5', 'split_1x4', False),
     ('vgg3x3_128_pool_c5', 'auto', False),
     ('vgg3x3_256_pool_c5', 'split_2x4', False), ('vgg3x3_256_pool_c5', 'split_2x2_p8', False), ('vgg3x3_256_pool_c5', 'auto', False),
+    ('small_pool', 'split_1x4', False), ('small_pool', 'auto', False), ('small_pool_128', 'split_2x2', False), ('small_pool_128', 'split_2x4', False),
+    ('small_res_out2', 'split_2x2', False), ('small_res_out2', 'split_2x4', False), ('small_prelu_256', 'split_2x2', False),
+    ('small_prelu_256', 'split_2x4', False), ('small_plain_1x1', 'split_2x2', False),
 ]
 
 _ref_cache = {}
