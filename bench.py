@@ -136,6 +136,8 @@ def main():
                     help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
                          'rocprofv3 kernel statistics under profiles/ are taken in, so that their per-kernel averages '
                          'are comparable with the HIP-event roofline figures')
+    ap.add_argument('--window', type=int, default=0,
+                    help='bounded run-ahead inside a pipeline: a task starts step i once all three finished step i - W (0 = unbounded)')
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
     ap.add_argument('--sustain-seconds', type=float, default=2.5, help='length of the `sustained` timed region')
     ap.add_argument('--single-process', action='store_true',
@@ -262,6 +264,27 @@ def run(args):
             src = [queue.Queue() for _ in range(3)]
             done = queue.Queue()
             WAIT = 300.0                                     # a task thread that died must not block the others forever
+            # bounded run-ahead (--window W): a task starts step i only once every task has finished step i - W, the
+            # way a live stream with W batches of buffering behaves.  Without it the light detector runs hundreds of
+            # milliseconds ahead, and the tail of the region is the pose network alone on the GPU with nothing filling
+            # its launch gaps and partial rounds.
+            W_ = args.window
+            prog = [0, 0, 0]
+            cv = threading.Condition()
+
+            def gate(who, i):
+                if W_ <= 0:
+                    return
+                with cv:
+                    if not cv.wait_for(lambda: min(prog) >= i - W_, timeout=WAIT):
+                        raise RuntimeError('pipeline stalled at step %d' % i)
+
+            def tick(who):
+                if W_ <= 0:
+                    return
+                with cv:
+                    prog[who] += 1
+                    cv.notify_all()
 
             def feeder():                                   # hands batch i to the three task threads
                 for _ in range(k):
@@ -271,28 +294,34 @@ def run(args):
 
             def detect_loop():
                 res = []
-                for _ in range(k):
+                for i in range(k):
+                    gate(0, i)
                     fr = src[0].get(timeout=WAIT) if reader else self.frames[0]
                     res.append(self.det(fr))
                     q.put(res[-1])
+                    tick(0)
                     if reader:
                         done.put(('det', (fr, res[-1])))
                 return res
 
             def embed_loop():
                 res = []
-                for _ in range(k):
+                for i in range(k):
+                    gate(1, i)
                     fr = src[1].get(timeout=WAIT) if reader else self.frames[1]
                     res.append(self.rec.model.call(fr, pick_faces(q.get(timeout=WAIT))))
+                    tick(1)
                     if reader:
                         done.put(('rec', res[-1]))
                 return res
 
             def pose_loop():
                 res = []
-                for _ in range(k):
+                for i in range(k):
+                    gate(2, i)
                     fr = src[2].get(timeout=WAIT) if reader else self.frames[2]
                     res.append(self.est(fr))
+                    tick(2)
                     if reader:
                         done.put(('est', res[-1]))
                 return res

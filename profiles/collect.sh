@@ -15,5 +15,8 @@ for P in bf16x3 f32; do
     timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${C}_$P -o c -- python $R/bench.py --steps 1 --warmup 1 --serial --no-cpu-baseline --single-mode --precision $P > $O/pmc_${C}_$P.log 2>&1
   done
 done
+# the pipelined headline under a kernel trace: how much of the timed region has 0 / 1 / 2 / 3+ kernels in flight
+timeout 600 rocprofv3 --kernel-trace -d $O/kt_pipelined -o k -- python $R/bench.py --steps 60 --warmup 6 --no-cpu-baseline --single-mode > $O/kt_pipelined.log 2>&1
+timeout 120 python $R/tools/busy_fraction.py $O/kt_pipelined/k_results.db 0.5 > $O/pipelined_busy.txt 2>&1
 timeout 600 python $R/profiles/summarize_round.py $O $O/summary 2>&1 | tail -40
 ls $O | head -40
