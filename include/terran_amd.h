@@ -173,7 +173,8 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
  * that the variant CAN run use it (layers it cannot run stay automatic); a packed model may also pin single convs to a
  * variant (ta_op_desc.variant, terran_amd/pack.py `variant=`), which fails with TA_E_INVALID when that kernel cannot run
  * the layer.  ta_debug_conv_counts reports (and optionally clears) the launches per variant since the last reset,
- * counts16[TA_CONV_*], so a parity test knows which kernels produced the numbers it compared.
+ * counts16[TA_CONV_*], so a parity test knows which kernels produced the numbers it compared (counts16[15]: how many
+ * of those launches ran the split-role kernels' compile-time specialised epilogue rather than the generic one).
  * Under TA_CONV_AUTO a frame's result does not depend on the batch it arrives in (every kernel the automatic choice
  * can give one layer sums in the same order); a forced preference keeps the parity tolerances but not that bit-level
  * batch invariance (the symmetric-wave kernels pair K differently inside a slab and take no K-split). */

@@ -1517,6 +1517,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     if (p.res) ok = ok && p.res_fmt == TA_FMT_SPLIT && fits(p.res_img, p.res_off0);
     if (p.out2) ok = ok && p.o2_fmt == TA_FMT_SPLIT && fits(p.o2_img, p.o2_off0);
     q.fast_drain = ok ? 1 : 0;
+    if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;     // slot 15: launches whose epilogue ran the specialised drain
   }
   static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
   q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;

@@ -205,7 +205,10 @@ class Context:
         """Debug: {variant name: conv launches since the last reset}."""
         c = np.zeros(16, np.int64)
         self.check(self.lib.ta_debug_conv_counts(self.h, ptr(c), int(reset)))
-        return {k: int(c[v]) for k, v in CONV_VARIANTS.items() if v and c[v]}
+        out = {k: int(c[v]) for k, v in CONV_VARIANTS.items() if v and c[v]}
+        if c[15]:
+            out['lean_epilogue'] = int(c[15])          # split-role launches that ran the specialised drain
+        return out
 
     def pose_debug(self, n, cap_peaks=1024, cap_conn=1024):
         """Debug taps of the last OpenPose run / grouping on this context -> (peaks, connections):
