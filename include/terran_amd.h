@@ -37,6 +37,8 @@ extern "C" {
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
 #define TA_E_OVERFLOW (-4)  /* a working limit of the whole call was hit (per-image pose limits: see ta_openpose_run) */
+#define TA_E_RANGE (-5)     /* f16x3 arithmetic mode only: an activation left the half-float range (|x| > 65504); no
+                             * numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
 
 #define TA_MODEL_RETINAFACE 1
 #define TA_MODEL_ARCFACE 2
@@ -187,6 +189,9 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
 #define TA_CONV_SPLIT_2x4 6    /* producer/consumer waves, 128 cout x 256 px (8 consumer waves)      */
 #define TA_CONV_SPLIT_1x4 7    /* producer/consumer waves, 64 cout x 256 px                          */
 int ta_debug_conv_variant(ta_ctx* ctx, int variant);
+/* f16x3 mode: after ta_model_forward_* (the debug taps; the task entry points do this themselves), wait for the stream
+ * and report whether an epilogue met |x| > 65504: TA_OK or TA_E_RANGE.  Clears the condition. */
+int ta_debug_range_check(ta_ctx* ctx);
 int ta_debug_conv_counts(ta_ctx* ctx, int64_t* counts16, int reset);
 
 #ifdef __cplusplus

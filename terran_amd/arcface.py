@@ -45,7 +45,7 @@ def align_matrix(landmarks):
     return align_matrices(np.asarray(landmarks)[None])[0]
 
 
-class ArcFace:
+class ArcFace(runtime.RangeFallback):
 
     def __init__(self, device=None, image_side=112, state=None, ctx=None, precision=None):
         if image_side != 112:
@@ -55,13 +55,14 @@ class ArcFace:
         self.image_side = image_side
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
         self.model = lib.Model(self.ctx, runtime.packed_program('arcface', state, self.precision))
+        self._init_fallback('arcface', state)
 
     # -- device entry points ---------------------------------------------------------------
     def embed_crops(self, crops, normalize=True):
         crops = np.ascontiguousarray(crops, dtype=np.uint8)
         out = np.empty((crops.shape[0], 512), np.float32)
-        self.ctx.check(self.ctx.lib.ta_arcface_embed_crops(self.model.h, lib.ptr(crops), crops.shape[0],
-                                                           int(normalize), lib.ptr(out)))
+        self._with_fallback(lambda model: self.ctx.check(self.ctx.lib.ta_arcface_embed_crops(
+            model.h, lib.ptr(crops), crops.shape[0], int(normalize), lib.ptr(out))))
         return out
 
     def embed_faces(self, frames, frame_index, matrices, normalize=True, return_crops=False):
@@ -71,8 +72,8 @@ class ArcFace:
         n = idx.shape[0]
         out = np.empty((n, 512), np.float32)
         crops = np.empty((n, 3, 112, 112), np.uint8) if return_crops else None
-        self.ctx.check(self.ctx.lib.ta_arcface_embed_faces(self.model.h, frames.h, lib.ptr(idx), lib.ptr(mats), n,
-                                                           int(normalize), lib.ptr(out), lib.ptr(crops)))
+        self._with_fallback(lambda model: self.ctx.check(self.ctx.lib.ta_arcface_embed_faces(
+            model.h, frames.h, lib.ptr(idx), lib.ptr(mats), n, int(normalize), lib.ptr(out), lib.ptr(crops))))
         return (out, crops) if return_crops else out
 
     # -- the reference call ------------------------------------------------------------------

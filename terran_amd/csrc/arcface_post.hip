@@ -99,8 +99,9 @@ static int embed_tail(ta_model* m, int n, int normalize, float* out) {
     TA_HIP(ctx, hipGetLastError());
   }
   TA_HIP(ctx, hipMemcpyAsync(out, E.dev, (size_t)n * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  TA_TRY(ta_range_enqueue(ctx));
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return TA_OK;
+  return ta_range_check(ctx);                    // f16x3: TA_E_RANGE when an activation left the half-float range
 }
 
 extern "C" {

@@ -43,6 +43,7 @@ extern "C" int ta_debug_trace_read(long long* out, int n) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Arithmetic modes of the MFMA inner loop (activation tensors are float32, or pre-split bf16 hi|lo words in the
 // bf16 modes: act_format.h):
@@ -51,10 +52,37 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //                 v_mfma_f32_32x32x16_bf16, f32 accumulate: ~1e-5 relative per product,
 //                 i.e. float32-class accuracy at 3/16 of the f32 MFMA cost.              833 TF-equivalent peak
 //   PREC_BF16   : hi*hi only (throughput mode, NOT within the 1e-3 parity bar).          2.5 PF peak
-// Weights are split at pack time ([hi x32 | lo x32] bf16 per 128-byte row).  Activations either arrive in the same
-// image (TA_FMT_SPLIT, written by the producer's epilogue) or are float32 and split in registers right after the
-// ds_read (v_cvt_pk_bf16_f32).
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
+//   PREC_F16X3  : the same three-product scheme with IEEE half words on v_mfma_f32_32x32x16_f16: x = hi + lo carries
+//                 22 significant bits, every product hi*hi / hi*lo / lo*hi is exact in the float32 accumulator and the
+//                 dropped lo*lo term is <= 2^-22 of the product -- below the rounding noise of a float32 dot product.
+//                 Same MFMA count and rate as PREC_BF16X3.  Half floats end at 65504: weights are packed times a power of
+//                 two per layer (their lo halves stay normal numbers; the epilogue multiplies the sums back, exactly) and
+//                 an epilogue that would store |x| > 65504 raises the context's range flag (TA_E_RANGE) instead.
+// Weights are split at pack time ([hi x32 | lo x32] 16-bit words per 128-byte row).  Activations either arrive in the
+// same image (TA_FMT_SPLIT / TA_FMT_SPLIT16, written by the producer's epilogue) or are float32 and split in registers
+// right after the ds_read.
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16X3 = 3 };
+__host__ __device__ constexpr bool prec_x3(int prec) { return prec == PREC_BF16X3 || prec == PREC_F16X3; }
+
+// one 32x32x16 MFMA on 16-bit operand fragments held as raw bits (bf16x8 is the container type for both formats)
+template <int PREC>
+__device__ __forceinline__ f32x16 ta_mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (PREC == PREC_F16X3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// float32 -> the mode's 16-bit word (round to nearest even) and back, for operands split in registers
+template <int PREC>
+__device__ __forceinline__ __bf16 ta_to16(float x) {
+  if constexpr (PREC == PREC_F16X3) return __builtin_bit_cast(__bf16, (_Float16)x);
+  else return (__bf16)x;
+}
+template <int PREC>
+__device__ __forceinline__ float ta_from16(__bf16 h) {
+  if constexpr (PREC == PREC_F16X3) return (float)__builtin_bit_cast(_Float16, h);
+  else return (float)h;
+}
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -102,6 +130,9 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
       for (int j = 0; j < 4; ++j) slope[a][j] = *(const f32x4*)(p.prelu + co_base + a * 32 + 8 * j);
   }
   const int co_max = p.cout - 4;
+  const float us = p.w_unscale;
+  float amax = 0.f;                               // f16x3: largest |x| stored.  EVERY output of that mode is checked, float32 ones
+                                                  // too -- a conv that reads them splits them into half floats in registers
 #pragma unroll
   for (int b = 0; b < WN_TILES; ++b) {
     const int pix_raw = pix_tile0 + b * 32 + (lane & 31);
@@ -117,7 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[a][j][e] = acc[a][b][4 * j + e] + bias[a][j][e];
+        for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, bias[a][j][e]);   // us == 1: acc + bias
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
       for (int a = 0; a < WM_TILES; ++a)
@@ -158,7 +189,11 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = co_base + a * 32 + 8 * j;
-          if (co < p.cout) ta_st4(o, p.out_ch + co, p.out_fmt, v[a][j]);
+          if (co < p.cout) {
+            ta_st4(o, p.out_ch + co, p.out_fmt, v[a][j]);
+            if (p.prec == PREC_F16X3)
+              amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[a][j][0]), fabsf(v[a][j][1]))), fmaxf(fabsf(v[a][j][2]), fabsf(v[a][j][3])));
+          }
         }
     }
     if (p.out2) {
@@ -180,11 +215,15 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
-            if (co < p.cout) ta_st4(o2, p.o2_ch + co, p.o2_fmt, z);
+            if (co < p.cout) {
+              ta_st4(o2, p.o2_ch + co, p.o2_fmt, z);
+              if (p.prec == PREC_F16X3) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
+            }
           }
       }
     }
   }
+  if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
 }
 
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
@@ -317,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a) {
           ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-          if constexpr (PREC == PREC_BF16X3) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+          if constexpr (prec_x3(PREC)) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
         }
 #pragma unroll
         for (int b = 0; b < WN_TILES; ++b) {
@@ -325,32 +364,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
           const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+            const __bf16 h0 = ta_to16<PREC>(x0[e]), h1 = ta_to16<PREC>(x1[e]);
             bh[b][e] = h0;
             bh[b][4 + e] = h1;
-            if constexpr (PREC == PREC_BF16X3) {
-              bl[b][e] = (__bf16)(x0[e] - (float)h0);
-              bl[b][4 + e] = (__bf16)(x1[e] - (float)h1);
+            if constexpr (prec_x3(PREC)) {
+              bl[b][e] = ta_to16<PREC>(x0[e] - ta_from16<PREC>(h0));
+              bl[b][4 + e] = ta_to16<PREC>(x1[e] - ta_from16<PREC>(h1));
             }
           }
         }
-        if constexpr (PREC == PREC_BF16X3) {
+        if constexpr (prec_x3(PREC)) {
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = ta_mfma16<PREC>(al[a], bh[b], acc[a][b]);
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = ta_mfma16<PREC>(ah[a], bl[b], acc[a][b]);
         }
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
           for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = ta_mfma16<PREC>(ah[a], bh[b], acc[a][b]);
       }
     }
   }
@@ -523,13 +562,13 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a) {
           f.ah[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-          if constexpr (PREC == PREC_BF16X3) f.al[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+          if constexpr (prec_x3(PREC)) f.al[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
         }
 #pragma unroll
         for (int b = 0; b < WN_TILES; ++b) {
           if constexpr (BSPLIT) {      // pre-split activations: same [hi | lo] row image as the weights
             f.bh[b][t] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-            if constexpr (PREC == PREC_BF16X3) f.bl[b][t] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+            if constexpr (prec_x3(PREC)) f.bl[b][t] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
           } else {
             f.b32[b][2 * t] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
             f.b32[b][2 * t + 1] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
@@ -547,12 +586,12 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float x0 = f.b32[b][2 * t][e], x1 = f.b32[b][2 * t + 1][e];
-            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+            const __bf16 h0 = ta_to16<PREC>(x0), h1 = ta_to16<PREC>(x1);
             f.bh[b][t][e] = h0;
             f.bh[b][t][4 + e] = h1;
-            if constexpr (PREC == PREC_BF16X3) {
-              f.bl[b][t][e] = (__bf16)(x0 - (float)h0);
-              f.bl[b][t][4 + e] = (__bf16)(x1 - (float)h1);
+            if constexpr (prec_x3(PREC)) {
+              f.bl[b][t][e] = ta_to16<PREC>(x0 - ta_from16<PREC>(h0));
+              f.bl[b][t][4 + e] = ta_to16<PREC>(x1 - ta_from16<PREC>(h1));
             }
           }
     }
@@ -571,23 +610,23 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        if constexpr (PREC == PREC_BF16X3) {
+        if constexpr (prec_x3(PREC)) {
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[a][t], f.bh[b][t], acc[a][b], 0, 0, 0);
+              acc[a][b] = ta_mfma16<PREC>(f.al[a][t], f.bh[b][t], acc[a][b]);
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a][t], f.bl[b][t], acc[a][b], 0, 0, 0);
+              acc[a][b] = ta_mfma16<PREC>(f.ah[a][t], f.bl[b][t], acc[a][b]);
         }
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
           for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a][t], f.bh[b][t], acc[a][b], 0, 0, 0);
+            acc[a][b] = ta_mfma16<PREC>(f.ah[a][t], f.bh[b][t], acc[a][b]);
       }
     }
   };
@@ -629,9 +668,9 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     if constexpr (PREC != PREC_F32 && !BSPLIT) {
       // hipcc otherwise emits the MFMAs back to back and the hi/lo split after them: pin an interleave
       // (all fragment reads first, then 1 MFMA : VPM VALU) so the split runs in the MFMA shadows.
-      constexpr int NREAD = 2 * (WM_TILES * (PREC == PREC_BF16X3 ? 2 : 1) + 2 * WN_TILES);
-      constexpr int NMFMA = 2 * WM_TILES * WN_TILES * (PREC == PREC_BF16X3 ? 3 : 1);
-      constexpr int VPM = (PREC == PREC_BF16X3 ? 58 : 30) * WN_TILES / NMFMA + 1;
+      constexpr int NREAD = 2 * (WM_TILES * (prec_x3(PREC) ? 2 : 1) + 2 * WN_TILES);
+      constexpr int NMFMA = 2 * WM_TILES * WN_TILES * (prec_x3(PREC) ? 3 : 1);
+      constexpr int VPM = (prec_x3(PREC) ? 58 : 30) * WN_TILES / NMFMA + 1;
       __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
       for (int i = 0; i < NMFMA; ++i) {
@@ -868,14 +907,22 @@ __device__ __forceinline__ ta_f32x8 ta_ld8(const float* pix, int ch, int fmt) { 
     r.b = *(const f32x4*)(pix + ch + 4);
     return r;
   }
-  const char* q = (const char*)pix + ((ch >> 5) << 7) + ((ch & 31) << 1);
+  const char* q = (const char*)pix + ta_split_chan(ch);
   const uint4 h = *(const uint4*)q, l = *(const uint4*)(q + 64);
   const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
   float v[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v[2 * i] = __uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16);
-    v[2 * i + 1] = __uint_as_float(hw[i] & 0xFFFF0000u) + __uint_as_float(lw[i] & 0xFFFF0000u);
+    float h0, h1, l0, l1;
+    if (fmt == TA_FMT_SPLIT16) {
+      ta_unpack2<true>(hw[i], h0, h1);
+      ta_unpack2<true>(lw[i], l0, l1);
+    } else {
+      ta_unpack2<false>(hw[i], h0, h1);
+      ta_unpack2<false>(lw[i], l0, l1);
+    }
+    v[2 * i] = h0 + l0;
+    v[2 * i + 1] = h1 + l1;
   }
   r.a = f32x4{v[0], v[1], v[2], v[3]};
   r.b = f32x4{v[4], v[5], v[6], v[7]};
@@ -887,21 +934,27 @@ __device__ __forceinline__ void ta_st8(float* pix, int ch, int fmt, const ta_f32
     *(f32x4*)(pix + ch + 4) = v.b;
     return;
   }
-  // two floats per v_cvt_pk_bf16_f32 (round to nearest even, same as the scalar conversion)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   const float x[8] = {v.a[0], v.a[1], v.a[2], v.a[3], v.b[0], v.b[1], v.b[2], v.b[3]};
   unsigned hw[4], lw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bf16x2 h = __builtin_convertvector((f32x2){x[2 * i], x[2 * i + 1]}, bf16x2);
-    hw[i] = __builtin_bit_cast(unsigned, h);
-    const f32x2 r = {x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u)};
-    lw[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    if (fmt == TA_FMT_SPLIT16) ta_pack2<true>(x[2 * i], x[2 * i + 1], hw[i], lw[i]);
+    else ta_pack2<false>(x[2 * i], x[2 * i + 1], hw[i], lw[i]);
   }
-  char* q = (char*)pix + ((ch >> 5) << 7) + ((ch & 31) << 1);
+  char* q = (char*)pix + ta_split_chan(ch);
   *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
   *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+// largest |x| among the n4 (1 or 2) stored 4-channel halves of v
+__device__ __forceinline__ float ta_absmax8(float m, const ta_f32x8& v, int n4) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v.a[e]));
+  if (n4 == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v.b[e]));
+  }
+  return m;
 }
 
 template <int BN>
@@ -931,6 +984,9 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   constexpr int RPI = NT / G;                      // pixel rows per pass of the workgroup
   const int k8 = tid % G, r0 = tid / G;
   const int co = ct0 + 8 * k8;
+  const float us = p.w_unscale;
+  float amax = 0.f;                                // f16x3: largest |x| stored (every output of that mode, see conv_epilogue)
+  const bool chk = p.prec == PREC_F16X3, chk2 = chk && p.out2;
   if (p.k_split > 1) {                             // K-split: raw sums of this K range -> partial[ks][pixel][coutp]
     float* dst = p.partial + (size_t)ks * p.M * p.coutp + co;
     for (int row = r0; row < BM && pt0 + row < p.M; row += RPI) {
@@ -969,8 +1025,8 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v.a[e] += bias0[e];
-        v.b[e] += bias1[e];
+        v.a[e] = __builtin_fmaf(v.a[e], us, bias0[e]);
+        v.b[e] = __builtin_fmaf(v.b[e], us, bias1[e]);
         if (p.act == TA_ACT_RELU) {
           v.a[e] = v.a[e] > 0.f ? v.a[e] : 0.f;
           v.b[e] = v.b[e] > 0.f ? v.b[e] : 0.f;
@@ -989,8 +1045,10 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
         float* o = p.out + (size_t)img * p.out_img + (size_t)qy * p.out_row + (size_t)qx * p.out_pix + p.out_off0;
         if (n4 == 2) ta_st8(o, p.out_ch + co, p.out_fmt, v);
         else ta_st4(o, p.out_ch + co, p.out_fmt, v.a);
+        if (chk) amax = ta_absmax8(amax, v, n4);
       }
     }
+    if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
     return;
   }
   int pix = pt0 + r0;
@@ -1005,8 +1063,8 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v.a[e] += bias0[e];
-      v.b[e] += bias1[e];
+      v.a[e] = __builtin_fmaf(v.a[e], us, bias0[e]);
+      v.b[e] = __builtin_fmaf(v.b[e], us, bias1[e]);
     }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
@@ -1040,6 +1098,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
     if (n4 == 2) ta_st8(o, p.out_ch + co, p.out_fmt, v);
     else ta_st4(o, p.out_ch + co, p.out_fmt, v.a);
+    if (chk) amax = ta_absmax8(amax, v, n4);
     if (p.out2) {
       float* o2 = p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0;
       ta_f32x8 z;
@@ -1050,6 +1109,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       }
       if (n4 == 2) ta_st8(o2, p.o2_ch + co, p.o2_fmt, z);
       else ta_st4(o2, p.o2_ch + co, p.o2_fmt, z.a);
+      if (chk2) amax = ta_absmax8(amax, z, n4);
     }
     x += RPI;                                        // next pass: RPI pixels further in raster order
     while (x >= p.Wo) {
@@ -1060,6 +1120,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       }
     }
   }
+  if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
 }
 
 // ---- the same phase 2, specialised at compile time for the three epilogues that carry the bf16 workloads (launcher
@@ -1067,21 +1128,20 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
 // pool, no K-split).  The generic drain above spends ~19 lane-instructions per output element on run-time flags and
 // 64-bit addressing and is VALU-issue-bound (tools/conv_trace.py); this one is ~2x leaner.  Same arithmetic, same
 // order, same bits.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8]) {
+// F16: the tensors are TA_FMT_SPLIT16 (half words); `amax` then collects the largest |x| stored (range flag)
+template <bool F16>
+__device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], float& amax) {
   unsigned hw[4], lw[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bf16x2v h = __builtin_convertvector((f32x2){x[2 * i], x[2 * i + 1]}, bf16x2v);
-    hw[i] = __builtin_bit_cast(unsigned, h);
-    const f32x2 r = {x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u)};
-    lw[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
-  }
+  for (int i = 0; i < 4; ++i) ta_pack2<F16>(x[2 * i], x[2 * i + 1], hw[i], lw[i]);
   *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
   *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  if constexpr (F16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));   // one v_max3_f32 per pair
+  }
 }
-template <int BN, int BM, int NT, int ACT, bool RES, bool POOL = false>     // RES: + shortcut, and the second (affine) output; POOL: fused 2x2 max-pool
+template <int BN, int BM, int NT, int ACT, bool RES, bool F16, bool POOL = false>     // RES: + shortcut, and the second (affine) output; POOL: fused 2x2 max-pool
 __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
   constexpr int NCH = BN / 4;
   constexpr int G = BN / 8;
@@ -1102,7 +1162,9 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     *(f32x4*)sh = *(const f32x4*)(p.shift2 + co);
     *(f32x4*)(sh + 4) = *(const f32x4*)(p.shift2 + co + 4);
   }
-  auto chan = [](int ch) { return (unsigned)(((ch >> 5) << 7) + ((ch & 31) << 1)); };
+  auto chan = [](int ch) { return ta_split_chan(ch); };
+  const float us = p.w_unscale;
+  float amax = 0.f;
   char* const ob = (char*)p.out + chan(p.out_ch + co);
   const char* const rb = RES ? (const char*)p.res + chan(p.res_ch + co) : nullptr;
   char* const o2b = RES ? (char*)p.out2 + chan(p.o2_ch + co) : nullptr;
@@ -1132,15 +1194,19 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      v[e] += bias[e];
+      if (F16) v[e] = __builtin_fmaf(v[e], us, bias[e]);      // weights were packed times 2^wscale_log2
+      else v[e] += bias[e];
       if (ACT == TA_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
       if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
     }
     if (RES) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[2 * i] += __uint_as_float(rh[i] << 16) + __uint_as_float(rl[i] << 16);
-        v[2 * i + 1] += __uint_as_float(rh[i] & 0xFFFF0000u) + __uint_as_float(rl[i] & 0xFFFF0000u);
+        float h0, h1, l0, l1;
+        ta_unpack2<F16>(rh[i], h0, h1);
+        ta_unpack2<F16>(rl[i], l0, l1);
+        v[2 * i] += h0 + l0;
+        v[2 * i + 1] += h1 + l1;
       }
     }
     if (POOL) {
@@ -1150,12 +1216,12 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], __shfl_xor(v[e], m));
     }
     if (!POOL || (row & 3) == 0)
-      ta_split_store8(ob + 4u * (unsigned)(img * p.out_img + y * p.out_row + x * p.out_pix + p.out_off0), v);
+      ta_split_store8<F16>(ob + 4u * (unsigned)(img * p.out_img + y * p.out_row + x * p.out_pix + p.out_off0), v, amax);
     if (RES) {
       float z[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = v[e] * sc[e] + sh[e];
-      ta_split_store8(o2b + 4u * (unsigned)(img * p.o2_img + y * p.o2_row + x * p.o2_pix + p.o2_off0), z);
+      ta_split_store8<F16>(o2b + 4u * (unsigned)(img * p.o2_img + y * p.o2_row + x * p.o2_pix + p.o2_off0), z, amax);
     }
     if (one_carry) {                                 // branch-free
       x += dx;
@@ -1176,28 +1242,31 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
       }
     }
   }
+  if constexpr (F16) {
+    if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
+  }
 }
 // picks the lean drain when the launch qualifies; false = run the generic one
-template <int BN, int BM, int NT>
+template <int BN, int BM, int NT, bool F16>
 __device__ __forceinline__ bool conv_drain_dispatch(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
   if (!p.fast_drain) return false;
   if (p.pool) {
     if constexpr (4 * (BN / 8) <= 64 && ((NT / (BN / 8)) & 3) == 0) {
       if (p.act == TA_ACT_RELU && !p.res && !p.out2) {
-        conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false, true>(p, lds, ct0, pt0, tid, HoWo);
+        conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false, F16, true>(p, lds, ct0, pt0, tid, HoWo);
         return true;
       }
     }
     return false;
   }
   if (!p.res && !p.out2) {
-    if (p.act == TA_ACT_RELU) conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false>(p, lds, ct0, pt0, tid, HoWo);
-    else if (p.act == TA_ACT_PRELU) conv_drain_fast<BN, BM, NT, TA_ACT_PRELU, false>(p, lds, ct0, pt0, tid, HoWo);
-    else conv_drain_fast<BN, BM, NT, TA_ACT_NONE, false>(p, lds, ct0, pt0, tid, HoWo);
+    if (p.act == TA_ACT_RELU) conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false, F16>(p, lds, ct0, pt0, tid, HoWo);
+    else if (p.act == TA_ACT_PRELU) conv_drain_fast<BN, BM, NT, TA_ACT_PRELU, false, F16>(p, lds, ct0, pt0, tid, HoWo);
+    else conv_drain_fast<BN, BM, NT, TA_ACT_NONE, false, F16>(p, lds, ct0, pt0, tid, HoWo);
     return true;
   }
   if (p.res && p.out2 && p.act == TA_ACT_NONE) {
-    conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true>(p, lds, ct0, pt0, tid, HoWo);
+    conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true, F16>(p, lds, ct0, pt0, tid, HoWo);
     return true;
   }
   return false;
@@ -1328,7 +1397,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
       bool done = false;
-      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo);
+      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), PREC == PREC_F16X3>(p, lds, ct0, pt0, tid, HoWo);
       if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
@@ -1369,12 +1438,12 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-      if constexpr (PREC == PREC_BF16X3) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      if constexpr (prec_x3(PREC)) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       f.bh[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-      if constexpr (PREC == PREC_BF16X3) f.bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      if constexpr (prec_x3(PREC)) f.bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
     }
   };
   auto mma = [&](const Frag& f) {
@@ -1390,23 +1459,23 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a32[a][g][e], f.b32[b][g][e], acc[a][b], 0, 0, 0);
       return;
     }
-    if constexpr (PREC == PREC_BF16X3) {
+    if constexpr (prec_x3(PREC)) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.al[a], f.bh[b], acc[a][b]);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bl[b], acc[a][b]);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bh[b], acc[a][b]);
   };
   constexpr int NREAD = PREC == PREC_BF16 ? 4 : 8;                               // ds_read_b128 per k-step
-  constexpr int NMMA = PREC == PREC_F32 ? 32 : (PREC == PREC_BF16X3 ? 12 : 4);   // MFMAs per k-step
+  constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : 4);         // MFMAs per k-step
   // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
   // use to save registers and exposes the LDS latency in front of every group of MFMAs
   auto pin = [&]() {
@@ -1454,7 +1523,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(7);                     // consumer: past E1
     bool done = false;
-    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo);
+    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), PREC == PREC_F16X3>(p, lds, ct0, pt0, tid, HoWo);
     if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
@@ -1473,7 +1542,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     for (int k = 0; k < p.k_split; ++k) {
       const f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * p.M + pix) * p.coutp + co);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += t[e];
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], p.w_unscale, v[e]);      // w_unscale == 1: v + t
     }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
@@ -1488,6 +1557,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     const int y = rem / p.Wo, x = rem - y * p.Wo;
     ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, p.out_ch + co,
            p.out_fmt, v);
+    if (p.prec == PREC_F16X3 && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) <= TA_F16_MAX))
+      *p.range_flag = 1;
   }
 }
 
@@ -1512,10 +1583,11 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;      // tools: A/B
     const long long n_img = p.Ho * p.Wo > 0 ? ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo) : 0;
     auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
-    bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == TA_FMT_SPLIT &&
+    constexpr int SPLIT_FMT = PREC == PREC_F16X3 ? TA_FMT_SPLIT16 : TA_FMT_SPLIT;
+    bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == SPLIT_FMT &&
               (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
-    if (p.res) ok = ok && p.res_fmt == TA_FMT_SPLIT && fits(p.res_img, p.res_off0);
-    if (p.out2) ok = ok && p.o2_fmt == TA_FMT_SPLIT && fits(p.o2_img, p.o2_off0);
+    if (p.res) ok = ok && p.res_fmt == SPLIT_FMT && fits(p.res_img, p.res_off0);
+    if (p.out2) ok = ok && p.o2_fmt == SPLIT_FMT && fits(p.o2_img, p.o2_off0);
     q.fast_drain = ok ? 1 : 0;
     if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;     // slot 15: launches whose epilogue ran the specialised drain
   }
@@ -1576,8 +1648,11 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   return TA_OK;
 }
 
-int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
-  if (p.M <= 0) return TA_OK;
+int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
+  if (p_in.M <= 0) return TA_OK;
+  ta_conv_launch p = p_in;
+  p.w_unscale = 1.f;
+  p.range_flag = ctx->range_flag;
   if (p.prec != PREC_F32 || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w || !p.dw_bias ||
       p.n_slabs * 32 < p.dw_c)
     return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 mode, float32 activations and 4-aligned channels");
@@ -1590,11 +1665,11 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p, double flops) {
 // ---- kernel selection ---------------------------------------------------------------------------------------------
 // Which variants can run this conv at all (a forced variant that cannot is an error, never a silent substitution).
 static bool variant_eligible(int v, const ta_conv_launch& p) {
-  const bool split_in = p.prec == PREC_F32 ? p.in_fmt == TA_FMT_F32 : p.in_fmt == TA_FMT_SPLIT;   // what the split-role kernel reads
+  const bool split_in = p.in_fmt == ta_split_fmt_of(p.prec);   // what the split-role kernel reads: float32 in f32 mode, else the mode's pre-split format
   const bool deep = p.uniform_k && p.n_slabs >= 2;
   switch (v) {
     case TA_CV_GENERIC: return p.in_fmt == TA_FMT_F32 && !p.group_cout;
-    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || p.prec != PREC_F32);
+    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || split_in);
     case TA_CV_PIPE128: return deep && p.coutp % 128 == 0 && !p.group_cout && p.in_fmt == TA_FMT_F32;
     case TA_CV_SPLIT_2x2:
     case TA_CV_SPLIT_2x2_P8:
@@ -1633,7 +1708,7 @@ static int launch_variant(ta_ctx* ctx, int v, const ta_conv_launch& p) {
       return launch_cfg<1, 4, 1, 1, PREC>(ctx, p);
     case TA_CV_PIPE64:
       if constexpr (PREC != PREC_F32) {
-        if (p.in_fmt == TA_FMT_SPLIT) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
+        if (p.in_fmt != TA_FMT_F32) return launch_pipe<1, 4, 2, 1, PREC, 3, true>(ctx, p);
       }
       return launch_pipe<1, 4, 2, 1, PREC, 3, false>(ctx, p);
     case TA_CV_PIPE128: return launch_pipe<2, 2, 2, 2, PREC, 3, false>(ctx, p);
@@ -1654,8 +1729,12 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   p.probe = ctx->conv_probe;
   if (p.k_split < 1 || !p.partial || no_ksplit) p.k_split = 1;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
-  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16)
+  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16 && p.prec != PREC_F16X3)
     return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
+  if (p.in_fmt != TA_FMT_F32 && p.in_fmt != ta_split_fmt_of(p.prec))
+    return ta_fail(ctx, TA_E_INVALID, "conv: input tensor format %d does not belong to precision mode %d", p.in_fmt, p.prec);
+  p.range_flag = ctx->range_flag;
+  if (!(p.w_unscale > 0.f)) p.w_unscale = 1.f;
   int v = p.variant;
   if (v != TA_CV_AUTO) {
     if (!variant_eligible(v, p))
@@ -1680,6 +1759,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   switch (p.prec) {
     case PREC_F32: return launch_variant<PREC_F32>(ctx, v, p);
     case PREC_BF16X3: return launch_variant<PREC_BF16X3>(ctx, v, p);
+    case PREC_F16X3: return launch_variant<PREC_F16X3>(ctx, v, p);
     default: return launch_variant<PREC_BF16>(ctx, v, p);
   }
 }

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void copych_kernel(const float* in, float* out
 
 int ta_launch_copych(ta_ctx* ctx, const ta_tensor& in, int in_ch, const ta_tensor& out, int out_ch, int ch, int n) {
   // raw 16-byte copies: with pre-split tensors the slice must be whole 32-channel blocks in the same format
-  if (in.fmt != out.fmt || (in.fmt == TA_FMT_SPLIT && ((in_ch | out_ch | ch) & 31)))
+  if (in.fmt != out.fmt || (in.fmt != TA_FMT_F32 && ((in_ch | out_ch | ch) & 31)))
     return ta_fail(ctx, TA_E_INVALID, "copych: incompatible tensor formats");
   const size_t total = (size_t)n * in.h * in.w * (ch / 4);
   if (!total) return TA_OK;

@@ -20,7 +20,7 @@ static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad -
 // operands in the bf16 modes) and its epilogue is plain (no residual, no second output).
 static bool conv_ksplit_eligible(const ta_op_desc& op, int in_fmt) {
   const bool uniform = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
-  const bool kernel_ok = op.prec == 0 ? in_fmt == TA_FMT_F32 : in_fmt == TA_FMT_SPLIT;
+  const bool kernel_ok = in_fmt == ta_split_fmt_of(op.prec);
   return uniform && kernel_ok && op.res < 0 && op.out2 < 0 && op.groups <= 1;
 }
 
@@ -155,7 +155,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
           const bool ok = op.cin % 32 == 0 && op.n_slabs == op.kh * op.kw * (op.cin / 32) && op.n_slabs >= 2 &&
                           op.cout % op.groups == 0 && (op.cout / op.groups) % 128 == 0 && op.cout == op.coutp &&
                           op.in_ch_off % 32 == 0 && op.in_ch_off + op.groups * op.cin <= ti.c &&
-                          (op.prec == 0 ? ti.fmt == TA_FMT_F32 : ti.fmt == TA_FMT_SPLIT);
+                          ti.fmt == ta_split_fmt_of(op.prec);
           if (!ok) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu: unsupported grouped convolution", oi);
         }
         [[fallthrough]];
@@ -194,7 +194,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
   }
   for (int i = 0; i < T; ++i) TA_TRY(resolve_alias(i));
   for (int i = 0; i < T; ++i)
-    if (ts[i].fmt == TA_FMT_SPLIT && ts[i].c % 32) return ta_fail(ctx, TA_E_INVALID, "plan: pre-split tensor %d has %d channels", i, ts[i].c);
+    if (ts[i].fmt != TA_FMT_F32 && ts[i].c % 32) return ta_fail(ctx, TA_E_INVALID, "plan: pre-split tensor %d has %d channels", i, ts[i].c);
 
   // carve the arena
   size_t total = 0;
@@ -371,6 +371,7 @@ int ta_model_run_ops(ta_model* m) {
           p.group_cin = op.cin;
         }
         p.variant = op.variant;
+        p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
           p.pool = 1;
@@ -467,7 +468,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 4) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 5) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -490,7 +491,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
     if (op.type == TA_OP_CONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
-            op.stride <= 0 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            op.stride <= 0 || op.wscale_log2 < -60 || op.wscale_log2 > 60 || (op.prec != 3 && op.wscale_log2 != 0) || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0));
@@ -596,16 +597,23 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
         {
           const int cc = ch_off + c;
           float v;
-          if (t.fmt == TA_FMT_SPLIT) {
+          if (t.fmt != TA_FMT_F32) {
             const char* b = (const char*)&host[t.off(i, y, x)] + ((cc >> 5) << 7) + ((cc & 31) << 1);
             uint16_t h16, l16;
             memcpy(&h16, b, 2);
             memcpy(&l16, b + 64, 2);
-            const uint32_t hb = (uint32_t)h16 << 16, lb = (uint32_t)l16 << 16;
-            float hf, lf;
-            memcpy(&hf, &hb, 4);
-            memcpy(&lf, &lb, 4);
-            v = hf + lf;
+            if (t.fmt == TA_FMT_SPLIT16) {
+              _Float16 hh, ll;
+              memcpy(&hh, &h16, 2);
+              memcpy(&ll, &l16, 2);
+              v = (float)hh + (float)ll;
+            } else {
+              const uint32_t hb = (uint32_t)h16 << 16, lb = (uint32_t)l16 << 16;
+              float hf, lf;
+              memcpy(&hf, &hb, 4);
+              memcpy(&lf, &lb, 4);
+              v = hf + lf;
+            }
           } else {
             v = host[t.off(i, y, x) + cc];
           }

@@ -762,7 +762,11 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
   mp.fmt = X.fmt;
   mp.h = X.h;
   mp.w = X.w;
-  return op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required);
+  TA_TRY(ta_range_enqueue(ctx));                 // behind the network, ahead of the grouping's syncs
+  const int rc = op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required);
+  if (rc != TA_OK && rc != TA_E_CAPACITY) return rc;
+  const int rr = ta_range_check(ctx);            // f16x3: TA_E_RANGE when an activation left the half-float range
+  return rr != TA_OK ? rr : rc;
 }
 
 int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w, double scale,

@@ -45,6 +45,19 @@ int ta_pinned(ta_ctx* ctx, size_t bytes, void** out) {
   return TA_OK;
 }
 
+// ---- f16x3 range flag -----------------------------------------------------------------------------
+int ta_range_enqueue(ta_ctx* ctx) {
+  TA_HIP(ctx, hipMemcpyAsync(ctx->range_flag_host, ctx->range_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  return TA_OK;
+}
+
+int ta_range_check(ta_ctx* ctx) {
+  if (!*ctx->range_flag_host) return TA_OK;
+  *ctx->range_flag_host = 0;
+  TA_HIP(ctx, hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->stream));
+  return ta_fail(ctx, TA_E_RANGE, "f16x3: an activation exceeded the half-float range (|x| > 65504); run this input in the f32 or bf16x3 mode");
+}
+
 // ---- profiling ---------------------------------------------------------------------------------
 static hipEvent_t get_event(ta_ctx* ctx) {
   if (!ctx->event_pool.empty()) {
@@ -111,6 +124,14 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   }
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
+  if (hipMalloc((void**)&ctx->range_flag, sizeof(int)) != hipSuccess || hipMemset(ctx->range_flag, 0, sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->range_flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    if (ctx->range_flag) (void)hipFree(ctx->range_flag);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TA_E_DEVICE;
+  }
+  *ctx->range_flag_host = 0;
   // measurement aids for tools/ (the shipped path leaves both unset)
   if (const char* e = getenv("TA_CONV_PREFER")) ctx->conv_force = atoi(e);
   if (const char* e = getenv("TA_CONV_PROBE")) ctx->conv_probe = atoi(e);
@@ -129,12 +150,22 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pose_wphase) (void)hipFree(ctx->pose_wphase);
+  if (ctx->range_flag) (void)hipFree(ctx->range_flag);
+  if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
   for (auto& e : ctx->frame_cache) (void)hipFree(e.second);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 const char* ta_last_error(const ta_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ta_debug_range_check(ta_ctx* ctx) {
+  ta_enter(ctx);
+  if (!ctx) return TA_E_INVALID;
+  TA_TRY(ta_range_enqueue(ctx));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ta_range_check(ctx);
+}
 
 int ta_ctx_sync(ta_ctx* ctx) {
   ta_enter(ctx);

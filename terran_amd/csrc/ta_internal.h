@@ -58,11 +58,12 @@ struct ta_op_desc {
   int32_t res, res_ch_off, res_up2;   // residual tensor (-1 none); res_up2: read residual at (y/2, x/2)
   int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
-  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (f32-class), 2 = bf16 (throughput)
+  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
   int32_t variant;                    // 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests)
   int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
-  int32_t reserved;
+  int32_t wscale_log2;                // f16x3: the packed weights are W * 2^wscale_log2 (their lo halves stay normal half floats);
+                                      // the epilogue multiplies the sums by 2^-wscale_log2 (exact).  0 in the other modes
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
@@ -117,7 +118,13 @@ struct ta_ctx {
   int conv_force = 0;
   int conv_probe = 0;                              // tools only (TA_CONV_PROBE): timing ablations of the split kernel
   int64_t conv_counts[16] = {0};
+  // f16x3: raised (device side) by a conv epilogue that met |x| > 65504 while writing a half-split tensor; copied to
+  // the pinned host word behind the results of a call (ta_range_enqueue) and turned into TA_E_RANGE (ta_range_check)
+  int* range_flag = nullptr;
+  int* range_flag_host = nullptr;
 };
+int ta_range_enqueue(ta_ctx* ctx);   // async copy of the flag on the context's stream (before the call's final sync)
+int ta_range_check(ta_ctx* ctx);     // after that sync: TA_OK, or TA_E_RANGE (and the flag is cleared for the next call)
 
 // Conv kernel variants (ta_debug_conv_variant / ta_debug_conv_counts; include/terran_amd.h lists them)
 enum {
@@ -235,7 +242,12 @@ struct ta_conv_launch {
   int fast_drain;                              // 1: the lean epilogue applies (split-format tensors below 4 GB, cout % 8 == 0, no pool / K-split)
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
+  float w_unscale;                             // sums are multiplied by this before the bias (2^-wscale_log2; 1 outside f16x3)
+  int* range_flag;                             // set to 1 by an epilogue that writes |x| > 65504 into a TA_FMT_SPLIT16 tensor
 };
+
+// the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
+static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : (prec == 3 ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */); }
 
 // K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
 // 128 x 128 at the batch sizes in use): K is cut in a FIXED number of ranges that depends on the layer only, never on

@@ -11,8 +11,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libterran_amd.so')
 
-OK, E_INVALID, E_DEVICE, E_CAPACITY, E_OVERFLOW = 0, -1, -2, -3, -4
-_CODES = {E_INVALID: 'TA_E_INVALID', E_DEVICE: 'TA_E_DEVICE', E_CAPACITY: 'TA_E_CAPACITY', E_OVERFLOW: 'TA_E_OVERFLOW'}
+OK, E_INVALID, E_DEVICE, E_CAPACITY, E_OVERFLOW, E_RANGE = 0, -1, -2, -3, -4, -5
+_CODES = {E_INVALID: 'TA_E_INVALID', E_DEVICE: 'TA_E_DEVICE', E_CAPACITY: 'TA_E_CAPACITY', E_OVERFLOW: 'TA_E_OVERFLOW',
+          E_RANGE: 'TA_E_RANGE'}
 
 
 class TerranAmdError(RuntimeError):
@@ -70,6 +71,7 @@ SIGNATURES = {
     'ta_openpose_debug_read': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p]),
     'ta_debug_conv_variant': (c_int, [c_void_p, c_int]),
+    'ta_debug_range_check': (c_int, [c_void_p]),
     'ta_debug_conv_counts': (c_int, [c_void_p, c_void_p, c_int]),
 }
 

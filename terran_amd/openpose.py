@@ -47,7 +47,7 @@ def _run(ctx, fn, n):
         return out
 
 
-class OpenPose:
+class OpenPose(runtime.RangeFallback):
 
     def __init__(self, device=None, short_side=184, state=None, ctx=None, precision=None):
         self.device = device
@@ -55,6 +55,7 @@ class OpenPose:
         self.short_side = short_side
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
         self.model = lib.Model(self.ctx, runtime.packed_program('openpose', state, self.precision))
+        self._init_fallback('openpose', state)
 
     def call_frames(self, frames):
         """frames: lib.Frames at ORIGINAL resolution; resized on the device to `short_side`."""
@@ -65,8 +66,8 @@ class OpenPose:
         nw, nh = int(W * scale), int(H * scale)                  # openpose/wrapper.py:95-99
         resized = frames if (nh, nw) == (H, W) else frames.resize(nh, nw, ctx=self.ctx)
         try:
-            return _run(self.ctx, lambda cap, *a: self.ctx.lib.ta_openpose_run(
-                self.model.h, resized.h, float(scale), cap, *a), n)
+            return self._with_fallback(lambda model: _run(self.ctx, lambda cap, *a: self.ctx.lib.ta_openpose_run(
+                model.h, resized.h, float(scale), cap, *a), n))
         finally:
             if resized is not frames:
                 resized.free()

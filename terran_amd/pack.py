@@ -31,16 +31,17 @@ HEADER_DT = np.dtype({
     'itemsize': 128,
 })
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
-FMT_F32, FMT_SPLIT = 0, 1
+FMT_F32, FMT_SPLIT, FMT_SPLIT16 = 0, 1, 2
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
-           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'reserved']
+           'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'wscale_log2']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 4            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`
+BLOB_VERSION = 5            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
-PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3}
+SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16}     # pre-split activation format per arithmetic mode
 
 
 def _rup(x, m):
@@ -64,6 +65,23 @@ def split_bf16_rows(packed):
     lo = _bf16_bits(packed - _bf16_to_f32(hi))
     rows = np.concatenate([hi, lo], axis=-1)                # (..., 64) uint16
     return np.ascontiguousarray(rows).view(np.float32)      # (..., 32)
+
+
+def split_f16_rows(packed):
+    """[slab][cout][32] float32 -> ([hi x32 | lo x32] IEEE half rows viewed as float32, wscale_log2).
+
+    Half floats carry 11 significant bits down to 2^-14 only; a lo half below that loses bits.  The whole layer is
+    therefore packed times 2^s, s chosen so that max |W| 2^s lies in [2^13, 2^14): every weight within 2^-16 of the
+    largest keeps a normal lo half (22 significant bits in hi + lo), and nothing gets near 65504.  The conv epilogue
+    multiplies the sums by 2^-s, which is exact."""
+    packed = np.ascontiguousarray(packed, dtype=np.float32)
+    m = float(np.abs(packed).max())
+    s = 0 if m == 0.0 or not np.isfinite(m) else int(np.clip(13 - np.floor(np.log2(m)), -40, 40))
+    scaled = np.ldexp(packed, s).astype(np.float32)               # exact (power of two)
+    hi = scaled.astype(np.float16)
+    lo = (scaled - hi.astype(np.float32)).astype(np.float16)
+    rows = np.concatenate([hi.view(np.uint16), lo.view(np.uint16)], axis=-1)
+    return np.ascontiguousarray(rows).view(np.float32), s
 
 
 class Program:
@@ -142,7 +160,10 @@ class Program:
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:K] = full.reshape(K, coutp)
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
-        if self.prec != 0:
+        wscale = 0
+        if self.prec == 3:
+            packed, wscale = split_f16_rows(packed)
+        elif self.prec != 0:
             packed = split_bf16_rows(np.ascontiguousarray(packed))
 
         def vec(v):
@@ -154,7 +175,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
-                  groups=groups, variant=variant, pool=int(bool(pool)), reserved=0, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, variant=variant, pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -165,7 +186,7 @@ class Program:
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
-                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=self._w(w9), bias_off=self._w(bias),
+                  out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(w9), bias_off=self._w(bias),
                   prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
@@ -179,7 +200,7 @@ class Program:
         assert blob.size == 448
         op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=16, coutp=32, kh=3, kw=3, stride=2,
                   pad=1, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1,
-                  variant=0, pool=0, reserved=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  variant=0, pool=0, wscale_log2=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
                   macs_per_pixel=float(8 * 27 + 16 * 8))
         op['in'] = tin
         self.ops.append(op)
@@ -202,7 +223,7 @@ class Program:
         w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  n_slabs=n_slabs, prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
                   scale2_off=self._w(w9), shift2_off=self._w(np.asarray(bd, np.float64)),
                   macs_per_pixel=float(cout * C))
         op['in'] = tin
@@ -211,7 +232,7 @@ class Program:
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
-                  prec=0, groups=1, variant=0, pool=0, reserved=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
+                  prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
                   macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)
@@ -249,7 +270,7 @@ class Program:
         conv consumers are whole-block reads by the pipelined kernel, whose MFMA operand fragments then come
         straight out of LDS with no conversion VALU.  Everything else stays float32."""
         n = len(self.tensors)
-        fmt = [FMT_SPLIT if (self.prec != 0 and self.allow_split and c % 32 == 0) else FMT_F32
+        fmt = [SPLIT_FMT[self.prec] if (self.allow_split and c % 32 == 0) else FMT_F32
                for c, _, _ in self.tensors]
         for t in self.f32_only | {self.input_tensor}:
             fmt[t] = FMT_F32
@@ -499,7 +520,7 @@ def pack_retinaface(sd, precision='f32', fused=None):
     # order of near-tied scores in 3 % of the images.  The graph is HBM-bound (35 FLOP/B), so the exact-f32 MFMA costs
     # next to nothing here: in the `bf16x3` mode the detector runs on it, and its results ARE the `f32` mode's, bit for
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
-    P = Program(MODEL_RETINAFACE, 'f32' if precision == 'bf16x3' else precision)
+    P = Program(MODEL_RETINAFACE, 'f32' if precision in ('bf16x3', 'f16x3') else precision)
     P.allow_split = False
     if fused is None:
         fused = P.prec == 0 and not os.environ.get('TERRAN_AMD_NO_FUSED_DETECTOR')       # A/B switch

@@ -54,12 +54,34 @@ def resolve_state(kind, state):
 
 
 def resolve_precision(precision=None):
-    """'f32' (exact-f32 MFMA; the parity mode), 'bf16x3' (split-bf16 MFMA, float32-class accuracy) or
-    'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f32'."""
+    """'f32' (exact-f32 MFMA; the parity mode), 'f16x3' (split-half MFMA: 22-bit operands, three MFMAs per product,
+    float32-grade results; half-float range, see TA_E_RANGE), 'bf16x3' (split-bf16 MFMA: 16-bit operands, float32 range)
+    or 'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f32'."""
     p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f32')
-    if p not in ('f32', 'bf16x3', 'bf16'):
+    if p not in ('f32', 'f16x3', 'bf16x3', 'bf16'):
         raise ValueError('unknown precision %r' % (p,))
     return p
+
+
+class RangeFallback:
+    """The `f16x3` mode keeps activations as two half floats: |x| > 65504 does not fit, and the library then fails the
+    call with TA_E_RANGE instead of returning numbers.  Wrappers route such a batch to a second model packed for the
+    exact-f32 MFMA (same weights, float32 range), built on first use; `fallbacks` counts how often that happened."""
+
+    def _init_fallback(self, kind, state):
+        self._fb_kind, self._fb_state, self._fb_model, self.fallbacks = kind, state, None, 0
+
+    def _with_fallback(self, fn):
+        """fn(model) -> result; re-run on the f32 model when the f16x3 one reports TA_E_RANGE."""
+        try:
+            return fn(self.model)
+        except lib.TerranAmdError as e:
+            if e.code != lib.E_RANGE:
+                raise
+        if self._fb_model is None:
+            self._fb_model = lib.Model(self.ctx, packed_program(self._fb_kind, self._fb_state, 'f32'))
+        self.fallbacks += 1
+        return fn(self._fb_model)
 
 
 def packed_program(kind, state, precision):

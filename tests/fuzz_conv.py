@@ -60,7 +60,7 @@ def main():
     bad = 0
     for i in range(n):
         case = draw(rng)
-        for prec in ('f32', 'bf16x3'):
+        for prec in ('f32', 'f16x3', 'bf16x3'):
             try:
                 test_conv(ctx, case, prec)
             except Exception as e:          # noqa: BLE001

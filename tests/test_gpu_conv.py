@@ -42,10 +42,10 @@ CASES = [
 
 
 # float32 MFMA is an exact fmaf chain; bf16x3 drops the lo*lo term (~1e-5 of sum|x*w|); bf16 keeps 8 bits
-TOLS = {'f32': 2e-4, 'bf16x3': 6e-4, 'bf16': 6e-2}
+TOLS = {'f32': 2e-4, 'f16x3': 2e-4, 'bf16x3': 6e-4, 'bf16': 6e-2}     # f16x3: 22-bit operands, float32-grade
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('precision', ['f32', 'f16x3', 'bf16x3', 'bf16'])
 @pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join('%s%s' % kv for kv in c.items()))
 def test_conv(ctx, case, precision):
     from terran_amd import lib

@@ -23,7 +23,7 @@ def ctx():
     c.close()
 
 
-NET_TOL = {'f32': 3e-5, 'bf16x3': 2e-4}
+NET_TOL = {'f32': 3e-5, 'f16x3': 3e-5, 'bf16x3': 2e-4}
 _prec = ['f32']
 
 
@@ -39,7 +39,7 @@ def _close(a, b, tol=None, what=''):
     return err
 
 
-PRECISIONS = ['f32', 'bf16x3']      # both parity-grade modes; 'bf16' (throughput mode) is not expected to pass
+PRECISIONS = ['f32', 'f16x3', 'bf16x3']      # both parity-grade modes; 'bf16' (throughput mode) is not expected to pass
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)

@@ -31,7 +31,7 @@ def ctx():
     return runtime.get_context(0)
 
 
-@pytest.fixture(scope='module', params=['f32', 'bf16x3'])
+@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3'])
 def precision(request):
     """Both parity-grade conv modes must pass every wrapper / facade test (bf16x3 is bench.py's headline mode)."""
     return request.param
