@@ -37,10 +37,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _unit_hash(src, headers, flags):
+    """What one object file must correspond to: its source, every header and the exact flags."""
+    import hashlib
+    h = hashlib.sha256(' '.join(flags).encode())
+    for f in [src] + sorted(headers):
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
+    """Rebuilds are driven by CONTENT hashes, not mtimes: every object carries a `.o.stamp` with the hash of its source,
+    all headers and its flags (a `git checkout` of older sources, or changed TA_EXTRA_FLAGS, recompiles it), and the
+    library's stamp is written only for a link of objects that all match the sources beside them."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'terran_amd.h'))
+    extra_all = os.environ.get('TA_EXTRA_FLAGS', '').split()
     objs = []
     procs = []
     for src in SOURCES:
@@ -49,25 +63,42 @@ def build(force=False, verbose=False):
             continue
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            extra = ['-ffp-contract=off'] if src.endswith('_post.hip') else []   # bit-exact float steps
-            cmd = [hipcc] + FLAGS + extra + os.environ.get('TA_EXTRA_FLAGS', '').split() + ['-c', s, '-o', o]
+        flags = FLAGS + (['-ffp-contract=off'] if src.endswith('_post.hip') else []) + extra_all   # _post: bit-exact float steps
+        want = _unit_hash(s, headers, flags)
+        try:
+            with open(o + '.stamp') as fh:
+                have = fh.read().strip()
+        except OSError:
+            have = None
+        if force or have != want or not os.path.exists(o):
+            cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+            if os.path.exists(o + '.stamp'):
+                os.remove(o + '.stamp')
+            procs.append((src, o, want, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, o, want, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+        with open(o + '.stamp', 'w') as fh:
+            fh.write(want + '\n')
         if verbose and out:
             print(out.decode(errors='replace'))
-    if force or procs or _stale(LIB, objs):
+    try:
+        with open(STAMP) as fh:
+            lib_ok = fh.read().strip() == source_hash() and not extra_all
+    except OSError:
+        lib_ok = False
+    if force or procs or not lib_ok or _stale(LIB, objs):
+        if os.path.exists(STAMP):
+            os.remove(STAMP)
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stdout.decode(errors='replace'))
-    with open(STAMP, 'w') as fh:                 # lib.load() refuses a binary that does not match the sources beside it
-        fh.write(source_hash() + '\n')
+        with open(STAMP, 'w') as fh:             # lib.load() refuses a binary that does not match the sources beside it
+            fh.write(source_hash() + '\n')
     return LIB
 
 

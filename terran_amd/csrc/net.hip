@@ -272,8 +272,12 @@ static void print_op_profile(ta_model* m, std::vector<hipEvent_t>& ev) {
     const ta_tensor& to = m->tensors[op.out];
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev[2 * oi], ev[2 * oi + 1]);
-    const double M = (double)m->run_n * to.h * to.w;
-    const double fl = op.type == TA_OP_CONV ? 2.0 * op.macs_per_pixel * M : 0.0;
+    const ta_tensor& ti = m->tensors[op.in];
+    // a conv with a fused 2x2 max-pool computes every pixel of the UNPOOLED map: count those, not the pooled output
+    const double M = op.type == TA_OP_CONV && op.pool
+                         ? (double)m->run_n * conv_out(ti.h, op.kh, op.stride, op.pad) * conv_out(ti.w, op.kw, op.stride, op.pad)
+                         : (double)m->run_n * to.h * to.w;
+    const double fl = (op.type == TA_OP_CONV || op.type == TA_OP_DWPW) ? 2.0 * op.macs_per_pixel * M : 0.0;
     tot_ms += ms;
     tot_fl += fl;
     fprintf(stderr, "op %3zu type %d k%dx%d s%d g%d cin %4d cout %4d  %3dx%-3d M %8.0f slabs %4d  %8.1f us %7.1f TF\n", oi, op.type, op.kh,

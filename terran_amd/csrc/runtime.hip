@@ -134,7 +134,9 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   *ctx->range_flag_host = 0;
   // measurement aids for tools/ (the shipped path leaves both unset)
   if (const char* e = getenv("TA_CONV_PREFER")) ctx->conv_force = atoi(e);
+#ifdef TA_TOOLS   // timing ablations that give WRONG results: only in a tools build (TA_EXTRA_FLAGS=-DTA_TOOLS), never in the shipped library
   if (const char* e = getenv("TA_CONV_PROBE")) ctx->conv_probe = atoi(e);
+#endif
   *out = ctx;
   return TA_OK;
 }

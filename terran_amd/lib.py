@@ -96,7 +96,11 @@ def load():
                 stamp = fh.read().strip()
         except OSError:
             stamp = None
-        if stamp != _build.source_hash() and not os.environ.get('TA_ALLOW_STALE_LIB'):
+        try:
+            current = _build.source_hash()
+        except OSError:                             # relocated package without its sources: nothing to compare with
+            current = stamp
+        if (stamp is None or stamp != current) and not os.environ.get('TA_ALLOW_STALE_LIB'):
             raise TerranAmdError(E_DEVICE, 'libterran_amd.so was not built from the sources in terran_amd/csrc '
                                            '(run `python -m terran_amd.build`)')
         lib = C.CDLL(LIB_PATH)

@@ -56,8 +56,9 @@ def resolve_state(kind, state):
 def resolve_precision(precision=None):
     """'f32' (exact-f32 MFMA; the parity mode), 'f16x3' (split-half MFMA: 22-bit operands, three MFMAs per product,
     float32-grade results; half-float range, see TA_E_RANGE), 'bf16x3' (split-bf16 MFMA: 16-bit operands, float32 range)
-    or 'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f32'."""
-    p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f32')
+    or 'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f16x3' (the detector is
+    exact f32 in every parity mode; ArcFace / OpenPose fall back to an exact-f32 twin on TA_E_RANGE, RangeFallback below)."""
+    p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f16x3')
     if p not in ('f32', 'f16x3', 'bf16x3', 'bf16'):
         raise ValueError('unknown precision %r' % (p,))
     return p

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/clock
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for P in f32 bf16x3; do
+for P in f32 f16x3 bf16x3; do
   timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/${P}_clk -o c -- python $R/tools/conv_bench.py $P > $O/${P}_clk.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $O/${P}_mfma -o c -- python $R/tools/conv_bench.py $P > $O/${P}_mfma.log 2>&1
   python - $O/${P}_clk/c_results.db $O/${P}_mfma/c_results.db $P <<'PY'

@@ -65,7 +65,7 @@ def bench(ctx, name, n, h, w, cin, cout, k, groups, precision, reps=20):
 
 if __name__ == '__main__':
     ctx = lib.Context(0)
-    precs = sys.argv[1:] or ['f32', 'bf16x3', 'bf16']
+    precs = sys.argv[1:] or ['f32', 'f16x3', 'bf16x3', 'bf16']
     for s in SHAPES:
         for p in precs:
             bench(ctx, *s, p)

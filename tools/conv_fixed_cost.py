@@ -40,7 +40,7 @@ def run(ctx, k, precision, c=128, n=32, h=23, w=40, reps=30, layers=4):
 
 if __name__ == '__main__':
     ctx = lib.Context(0)
-    prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16x3'
+    prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
     stem = run(ctx, 1, prec, layers=0)
     xs, ys = [], []
     for k in (1, 3, 5, 7):

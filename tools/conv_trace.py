@@ -14,7 +14,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cin, cout = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (128, 128)
 n, h, w = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (32, 23, 40)
 rng = np.random.default_rng(0)
-P = pack.Program(pack.MODEL_OPENPOSE, 'bf16x3')
+P = pack.Program(pack.MODEL_OPENPOSE, 'f16x3')
 t0 = P.tensor(4, 1)
 P.input_tensor = t0
 t1 = P.tensor(cin, k // 2)

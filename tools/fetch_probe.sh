@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/fetchprobe
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for P in f32 bf16x3; do
+for P in f32 f16x3 bf16x3; do
   for V in 4 6; do
     TA_CONV_PREFER=$V timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${P}_v$V -o c -- python $R/tools/conv_bench.py $P > $O/${P}_v$V.log 2>&1
   done

@@ -11,7 +11,7 @@ from terran_amd import Detection, Recognition, Estimation, synth, weights   # no
 
 
 def main():
-    prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16x3'
+    prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
     sd = (weights.make_retinaface_state(), weights.make_arcface_state(), weights.make_openpose_decoder_state())
     det = Detection(device=0, state=sd[0], precision=prec)
     rec = Recognition(device=0, state=sd[1], precision=prec)

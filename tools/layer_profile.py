@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np                                                      # noqa: E402
 from terran_amd import lib, pack, synth, weights                         # noqa: E402
 
-prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16x3'
+prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
 ctx = lib.Context(0)
 for name, packer, sd, shape in (('openpose', pack.pack_openpose, weights.make_openpose_decoder_state(), (32, 184, 327)),
                                 ('retinaface', pack.pack_retinaface, weights.make_retinaface_state(), (32, 416, 739))):

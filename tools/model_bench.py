@@ -1,6 +1,6 @@
 """Per-model throughput at SURVEY.md 8's shapes C2 / C3 / C4 (run on the GPU box).
 
-    python tools/model_bench.py [--out gpurun_out/per_model.json] [--precisions bf16x3 f32]
+    python tools/model_bench.py [--out gpurun_out/per_model.json] [--precisions f16x3 f32]
 
 C2  RetinaFace   32 x 640 x 640   frames resident in HBM -> network + decode + sort + NMS + result download
 C3  ArcFace      256 x 3 x 112 x 112 BGR crops (host)    -> upload + network + L2 norm + download (0.7 MB/crop: PCIe-light)
@@ -47,7 +47,7 @@ def timed(ctx, fn, reps, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=None)
-    ap.add_argument('--precisions', nargs='+', default=['bf16x3', 'f32'])
+    ap.add_argument('--precisions', nargs='+', default=['f16x3', 'f32'])
     ap.add_argument('--reps', type=int, default=5)
     args = ap.parse_args()
     ctx = runtime.get_context(0)
