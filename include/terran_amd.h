@@ -36,7 +36,7 @@ extern "C" {
 #define TA_E_INVALID (-1)   /* bad argument / malformed model blob            */
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
-#define TA_E_OVERFLOW (-4)  /* a working limit of the whole call was hit (per-image pose limits: see ta_openpose_run) */
+#define TA_E_OVERFLOW (-4)  /* an addressing limit was hit (ta_openpose_run: more than 65535 peaks of ONE body part in one image) */
 #define TA_E_RANGE (-5)     /* f16x3 arithmetic mode only: an activation left the half-float range (|x| > 65504); no
                              * numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
 
@@ -139,10 +139,11 @@ int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int 
 /* frames: uint8 RGB ALREADY at network resolution (the wrapper's resize is ta_frames_resize);
  * scale = short_side / min(H_orig, W_orig) maps keypoints back ((coord/scale) truncated).
  * keypoints: (M,18,3) int32 (x, y, present); scores: (M,) float64; counts[i] humans of image i.
- * The grouping kernels hold at most 1024 peaks per part, 8192 candidate pairs per limb and 192 people under assembly
- * per image (the reference has no such limits; they are ~50x anything a real frame produces): an image over one of
- * them does not fail the call -- its count is -1 and it contributes no rows, the other images' results stand, and
- * ta_last_error names the condition. */
+ * No caps, like the reference (wrapper.py:235-262,335-366): the grouping kernels' fast path keeps 1024 peaks per part,
+ * 8192 candidate pairs per limb and 192 people under assembly per image in LDS (~50x what a real frame produces); an
+ * image that outgrows them -- a saturated heat-map plateau does -- is recomputed alone with lists in global memory sized
+ * from its own counts, and network-resolution maps too large for the LDS staging (beyond ~90 x 160 cells) take the same
+ * global-memory kernels for the whole batch.  Only > 65535 peaks of one part in one image fail (TA_E_OVERFLOW). */
 int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capacity,
                     int32_t* counts, int32_t* keypoints, double* scores, int32_t* required);
 /* Grouping only (x8 bicubic, peaks, PAF scoring, greedy matching, assembly) on host maps at

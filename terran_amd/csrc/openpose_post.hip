@@ -18,6 +18,11 @@
 #include "act_format.h"
 #include "ta_internal.h"
 
+// Working sizes of the FAST path (lists in LDS).  They are not limits: an image that outgrows one of them -- a saturated
+// heat-map plateau does -- is re-run alone on the <BIG = true> instantiations of the same kernels, whose lists live in
+// global memory and are sized from the counts the first pass reported (wrapper.py:235-262,335-366 have no caps), and
+// network-resolution maps too large for the LDS staging (short sides beyond ~730 on 16:9 input) take those kernels for
+// the whole batch, reading a planar float32 copy of the maps instead.
 #define OP_MAXP 1024       // peaks per (image, part)
 #define OP_MAXC 8192       // accepted pair candidates per (image, limb)
 #define OP_MAXH 192        // humans under assembly per image
@@ -145,17 +150,29 @@ struct op_work {
   op_maps m;           // network-resolution maps (NHWC)
   const float* wphase; // [8][4] cubic weights per output phase (same table for x and y: they depend on the phase only)
   int N, H8, W8;
-  int* peak_cnt;       // [N][18]
-  int* peak_yx;        // [N][18][OP_MAXP][2]
-  float* peak_sc;      // [N][18][OP_MAXP]
+  int img_base;        // work-area image i is image img_base + i of the maps
+  int maxp, maxc, maxh; // list capacities (OP_MAXP / OP_MAXC / OP_MAXH on the fast path)
+  int* peak_cnt;       // [N][18]   (min(true count, maxp))
+  int* peak_true;      // [N][18]   the number of peaks found, capped or not
+  int* peak_yx;        // [N][18][maxp][2]
+  float* peak_sc;      // [N][18][maxp]
   int* conn_cnt;       // [N][19]   (-1 = limb missing)
-  int* conn_ij;        // [N][19][OP_MAXP][2]
-  float* conn_sc;      // [N][19][OP_MAXP]
-  int* overflow;       // [N] image i ran into one of the caps above (its result is dropped, the others stand)
+  int* pair_true;      // [N][19]   accepted pair candidates of the limb, capped or not
+  int* conn_ij;        // [N][19][maxp][2]
+  float* conn_sc;      // [N][19][maxp]
+  int* overflow;       // [N] image i outgrew a list (its result is dropped here and recomputed with larger ones)
   double scale;
   int* out_cnt;        // [N]
-  int* out_kp;         // [N][OP_MAXH][18][3]
-  double* out_sc;      // [N][OP_MAXH]
+  int* out_kp;         // [N][maxh][18][3]
+  double* out_sc;      // [N][maxh]
+  // <BIG> kernels only: lists in global memory, maps as a planar float32 copy
+  const float* planar;          // [N][57][h][w]: PAF channels 0..37, heat-maps 38..56
+  unsigned long long* g_cand;   // [N][18][cand_pitch], cand_pitch = maxp rounded up to a power of two (bitonic sort in place)
+  int cand_pitch;
+  unsigned long long* g_keys;   // [N][19][maxc rounded up to a power of two]; nullptr = limbs_kernel only counts (pair_true)
+  unsigned* g_seen;             // [N][19][(maxp + 31) / 32]
+  double* g_humans;             // [N][maxh][20]
+  int keys_pitch;               // elements per (image, limb) of g_keys
 };
 
 // ATen's 4-tap accumulation (see bicubic_kernel): fma(v3,w3, fma(v2,w2, fma(v0,w0, v1*w1)))
@@ -191,17 +208,40 @@ __device__ __forceinline__ float op_up_at(const float* sm, int h, int w, int Y, 
 // block pixels, and appends the peaks to an LDS list; the list is then sorted by pixel index = the reference's row-major
 // `nonzero` order (wrapper.py:241-262).
 #define PK_T 512
+// planar float32 copy of the 57 network-resolution maps (the <BIG> kernels read it instead of staging maps in LDS)
+__global__ __launch_bounds__(256) void op_planar_kernel(const op_maps m, int img_base, int N, float* out) {
+  const size_t cells = (size_t)m.h * m.w, total = (size_t)N * 57 * cells;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cell = (int)(i % cells);
+    const int c = (int)((i / cells) % 57), img = (int)(i / (cells * 57));
+    const float* src = m.base + (size_t)(img_base + img) * m.img + m.off0 + (size_t)(cell / m.w) * m.row + (size_t)(cell % m.w) * m.pix;
+    out[i] = ta_ld1(src, c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38), m.fmt);
+  }
+}
+
+template <bool BIG>
 __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int h = w.m.h, wd = w.m.w;
-  float* sm = (float*)psm;                                         // h * wd
-  float4* wph = (float4*)(psm + (((size_t)h * wd * 4 + 15) & ~(size_t)15));   // 8
-  unsigned long long* cand = (unsigned long long*)(wph + 8);       // OP_MAXP
-  __shared__ int s_count;
   const int part = blockIdx.x % 18, img = blockIdx.x / 18;
   const int tid = threadIdx.x;
-  const float* src = w.m.base + (size_t)img * w.m.img + w.m.off0;
-  for (int i = tid; i < h * wd; i += PK_T) sm[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt);
+  const int maxp = BIG ? w.maxp : OP_MAXP;
+  const float* sm;
+  float4* wph;
+  unsigned long long* cand;
+  __shared__ int s_count;
+  if constexpr (BIG) {
+    wph = (float4*)psm;
+    sm = w.planar + ((size_t)img * 57 + 38 + part) * h * wd;
+    cand = w.g_cand + ((size_t)img * 18 + part) * w.cand_pitch;
+  } else {
+    float* smw = (float*)psm;                                        // h * wd
+    wph = (float4*)(psm + (((size_t)h * wd * 4 + 15) & ~(size_t)15));   // 8
+    cand = (unsigned long long*)(wph + 8);                           // OP_MAXP
+    const float* src = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
+    for (int i = tid; i < h * wd; i += PK_T) smw[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt);
+    sm = smw;
+  }
   if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
   if (tid == 0) s_count = 0;
   __syncthreads();
@@ -241,7 +281,7 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
             const float v = b[xx];
             if (X >= 1 && X <= W8 - 2 && v >= a[xx] && v >= b[xx - 1] && v >= c[xx] && v >= b[xx + 1] && v >= 0.1f) {
               const int pos = atomicAdd(&s_count, 1);
-              if (pos < OP_MAXP) cand[pos] = ((unsigned long long)(unsigned)(Y * W8 + X) << 32) | __float_as_uint(v);
+              if (pos < maxp) cand[pos] = ((unsigned long long)(unsigned)(Y * W8 + X) << 32) | __float_as_uint(v);
             }
           }
         }
@@ -250,11 +290,12 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
   }
   __syncthreads();
   int C = s_count;
-  if (C > OP_MAXP) {
+  if (tid == 0) w.peak_true[img * 18 + part] = C;
+  if (C > maxp) {
     if (tid == 0) atomicExch(w.overflow + img, 1);
-    C = OP_MAXP;
+    C = maxp;
   }
-  int P = 1;
+  int P = 1;                                       // (the list's storage is a power of two >= maxp: cand_pitch)
   while (P < C) P <<= 1;
   for (int i = C + tid; i < P; i += PK_T) cand[i] = ~0ull;
   __syncthreads();
@@ -272,8 +313,8 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
       }
       __syncthreads();
     }
-  int* yx = w.peak_yx + ((size_t)img * 18 + part) * OP_MAXP * 2;
-  float* sc = w.peak_sc + ((size_t)img * 18 + part) * OP_MAXP;
+  int* yx = w.peak_yx + ((size_t)img * 18 + part) * maxp * 2;
+  float* sc = w.peak_sc + ((size_t)img * 18 + part) * maxp;
   for (int i = tid; i < C; i += PK_T) {
     const unsigned long long key = cand[i];
     const int pix = (int)(unsigned)(key >> 32);
@@ -290,49 +331,68 @@ __device__ __forceinline__ int lin_trunc(float a, float b, float step, int i) {
   return (int)truncf(v);
 }
 
+// BIG: lists in global memory; w.g_keys == nullptr makes it a counting pass (pair_true only: sizes the keys of the real pass)
+template <bool BIG>
 __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* keys = (unsigned long long*)smem;               // OP_MAXC
-  unsigned* seen = (unsigned*)(smem + (size_t)OP_MAXC * 8);           // OP_MAXP bits
-  int* wave_tot = (int*)(seen + OP_MAXP / 32);                        // 4 + 1 (+ 3 pad)
-  int& s_base = wave_tot[4];
-  float4* wph = (float4*)(wave_tot + 8);                              // 8 phase weight sets
-  float* smx = (float*)(wph + 8);                                     // the limb's two PAF channels at network resolution
-  float* smy = smx + w.m.h * w.m.w;
-
   const int limb = blockIdx.x % 19, img = blockIdx.x / 19;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ks = c_limbseq[limb][0] - 1, kd = c_limbseq[limb][1] - 1;
-  const int ns = w.peak_cnt[img * 18 + ks], nd = w.peak_cnt[img * 18 + kd];
-  int* conn_ij = w.conn_ij + ((size_t)img * 19 + limb) * OP_MAXP * 2;
-  float* conn_sc = w.conn_sc + ((size_t)img * 19 + limb) * OP_MAXP;
-  if (ns == 0 || nd == 0) {
-    if (tid == 0) w.conn_cnt[img * 19 + limb] = -1;     // "missing limb" (wrapper.py:293-296)
-    return;
-  }
-  const int* syx = w.peak_yx + ((size_t)img * 18 + ks) * OP_MAXP * 2;
-  const int* dyx = w.peak_yx + ((size_t)img * 18 + kd) * OP_MAXP * 2;
-  const float half_h = (float)(0.5 * (double)w.H8);
-  {
-    const int mh = w.m.h, mw = w.m.w;
-    const float* srcm = w.m.base + (size_t)img * w.m.img + w.m.off0;
-    const int chx = w.m.paf_ch + c_map_idx[limb][0] - 19, chy = w.m.paf_ch + c_map_idx[limb][1] - 19;
+  const int maxp = BIG ? w.maxp : OP_MAXP, maxc = BIG ? w.maxc : OP_MAXC;
+  unsigned long long* keys;
+  unsigned* seen;
+  int* wave_tot;
+  float4* wph;
+  const float *smx, *smy;
+  const int mh = w.m.h, mw = w.m.w;
+  const int chx = c_map_idx[limb][0] - 19, chy = c_map_idx[limb][1] - 19;      // PAF channel pair of the limb
+  if constexpr (BIG) {
+    wave_tot = (int*)smem;                                              // 4 + 1 (+ 3 pad)
+    wph = (float4*)(wave_tot + 8);
+    keys = w.g_keys ? w.g_keys + ((size_t)img * 19 + limb) * w.keys_pitch : nullptr;
+    seen = w.g_seen + ((size_t)img * 19 + limb) * ((maxp + 31) / 32);
+    smx = w.planar + ((size_t)img * 57 + chx) * mh * mw;
+    smy = w.planar + ((size_t)img * 57 + chy) * mh * mw;
+  } else {
+    keys = (unsigned long long*)smem;                                   // OP_MAXC
+    seen = (unsigned*)(smem + (size_t)OP_MAXC * 8);                     // OP_MAXP bits
+    wave_tot = (int*)(seen + OP_MAXP / 32);
+    wph = (float4*)(wave_tot + 8);                                      // 8 phase weight sets
+    float* sx = (float*)(wph + 8);                                      // the limb's two PAF channels at network resolution
+    float* sy = sx + mh * mw;
+    const float* srcm = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
     for (int i = tid; i < mh * mw; i += 256) {
       const float* px = srcm + (size_t)(i / mw) * w.m.row + (size_t)(i % mw) * w.m.pix;
-      smx[i] = ta_ld1(px, chx, w.m.fmt);
-      smy[i] = ta_ld1(px, chy, w.m.fmt);
+      sx[i] = ta_ld1(px, w.m.paf_ch + chx, w.m.fmt);
+      sy[i] = ta_ld1(px, w.m.paf_ch + chy, w.m.fmt);
     }
-    if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
+    smx = sx;
+    smy = sy;
   }
+  int& s_base = wave_tot[4];
+  const int ks = c_limbseq[limb][0] - 1, kd = c_limbseq[limb][1] - 1;
+  const int ns = w.peak_cnt[img * 18 + ks], nd = w.peak_cnt[img * 18 + kd];
+  int* conn_ij = w.conn_ij + ((size_t)img * 19 + limb) * maxp * 2;
+  float* conn_sc = w.conn_sc + ((size_t)img * 19 + limb) * maxp;
+  if (ns == 0 || nd == 0) {
+    if (tid == 0) {
+      w.conn_cnt[img * 19 + limb] = -1;     // "missing limb" (wrapper.py:293-296)
+      w.pair_true[img * 19 + limb] = 0;
+    }
+    return;
+  }
+  const int* syx = w.peak_yx + ((size_t)img * 18 + ks) * maxp * 2;
+  const int* dyx = w.peak_yx + ((size_t)img * 18 + kd) * maxp * 2;
+  const float half_h = (float)(0.5 * (double)w.H8);
+  if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
   if (tid == 0) s_base = 0;
   __syncthreads();
-  const int total = ns * nd;
-  for (int t0 = 0; t0 < total; t0 += 256) {
-    const int t = t0 + tid;
+  const unsigned total = (unsigned)ns * (unsigned)nd;       // the launcher keeps ns, nd <= 65535
+  for (unsigned t0 = 0; t0 < total; t0 += 256) {
+    const unsigned t = t0 + tid;
     bool ok = false;
     float reg = 0.f;
     if (t < total) {
-      const int i = t / nd, j = t - i * nd;
+      const int i = (int)(t / (unsigned)nd), j = (int)(t - (unsigned)i * (unsigned)nd);
       const int sy = syx[i * 2], sx = syx[i * 2 + 1], ty = dyx[j * 2], tx = dyx[j * 2 + 1];
       const float dyf = (float)(ty - sy), dxf = (float)(tx - sx);
       // correctly rounded float sqrt (v_sqrt_f32 alone is 1 ulp): go through float64; the argument is an integer
@@ -359,23 +419,25 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
     __syncthreads();
     int off = s_base;
     for (int k = 0; k < wv; ++k) off += wave_tot[k];
-    if (ok) {
+    if (ok && (!BIG || keys)) {
       const int pos = off + before;
-      if (pos < OP_MAXC) keys[pos] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(reg)) << 32) | (unsigned)t;
+      if (pos < maxc) keys[pos] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(reg)) << 32) | (unsigned)t;
     }
     __syncthreads();
     if (tid == 0) s_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     __syncthreads();
   }
   int C = s_base;
-  if (C > OP_MAXC) {
+  if (tid == 0) w.pair_true[img * 19 + limb] = C;
+  if (BIG && !keys) return;                         // counting pass
+  if (C > maxc) {
     if (tid == 0) atomicExch(w.overflow + img, 1);
-    C = OP_MAXC;
+    C = maxc;
   }
   int P = 1;
   while (P < C) P <<= 1;
   for (int i = C + tid; i < P; i += 256) keys[i] = ~0ull;
-  for (int i = tid; i < OP_MAXP / 32; i += 256) seen[i] = 0;
+  for (int i = tid; i < (maxp + 31) / 32; i += 256) seen[i] = 0;
   __syncthreads();
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -398,8 +460,8 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
     int n = 0;
     for (int c = 0; c < C; ++c) {
       const unsigned long long key = keys[c];
-      const int t = (int)(unsigned)(key & 0xFFFFFFFFull);
-      const int i = t / nd, j = t - i * nd;
+      const unsigned t = (unsigned)(key & 0xFFFFFFFFull);
+      const int i = (int)(t / (unsigned)nd), j = (int)(t - (unsigned)i * (unsigned)nd);
       if (((seen[i >> 5] >> (i & 31)) & 1u) || ((seen[j >> 5] >> (j & 31)) & 1u)) continue;
       conn_ij[n * 2] = i;
       conn_ij[n * 2 + 1] = j;
@@ -416,10 +478,15 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
 // ---- 4. assembly -------------------------------------------------------------------------------------
 // humans[h][0..17] = global peak id or -1; [18] = score sum; [19] = keypoint count (all float64, as the
 // reference's numpy array).  One wavefront per image; lane-parallel search for matching humans.
+template <bool BIG>
 __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
-  __shared__ double humans[OP_MAXH][20];
+  __shared__ double humans_lds[BIG ? 1 : OP_MAXH][20];
   __shared__ int offs[19];
   const int img = blockIdx.x, lane = threadIdx.x;
+  const int maxp = BIG ? w.maxp : OP_MAXP, maxh = BIG ? w.maxh : OP_MAXH;
+  double (*humans)[20];
+  if constexpr (BIG) humans = (double (*)[20])(w.g_humans + (size_t)img * maxh * 20);
+  else humans = humans_lds;
   if (lane == 0) {
     int o = 0;
     for (int p = 0; p < 18; ++p) {
@@ -435,10 +502,10 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
     const int nc = w.conn_cnt[img * 19 + limb];
     if (nc < 0) continue;
     const int ks = c_limbseq[limb][0] - 1, kd = c_limbseq[limb][1] - 1;
-    const int* cij = w.conn_ij + ((size_t)img * 19 + limb) * OP_MAXP * 2;
-    const float* csc = w.conn_sc + ((size_t)img * 19 + limb) * OP_MAXP;
-    const float* psc_d = w.peak_sc + ((size_t)img * 18 + kd) * OP_MAXP;
-    const float* psc_s = w.peak_sc + ((size_t)img * 18 + ks) * OP_MAXP;
+    const int* cij = w.conn_ij + ((size_t)img * 19 + limb) * maxp * 2;
+    const float* csc = w.conn_sc + ((size_t)img * 19 + limb) * maxp;
+    const float* psc_d = w.peak_sc + ((size_t)img * 18 + kd) * maxp;
+    const float* psc_s = w.peak_sc + ((size_t)img * 18 + ks) * maxp;
     for (int c = 0; c < nc; ++c) {
       const int i = cij[c * 2], j = cij[c * 2 + 1];
       const double a = (double)(offs[ks] + i), b = (double)(offs[kd] + j);
@@ -488,7 +555,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
           humans[first][18] += peak_b + s;
         }
       } else if (nmatch == 0 && limb < 17) {
-        if (nh < OP_MAXH) {
+        if (nh < maxh) {
           if (lane < 18) humans[nh][lane] = -1.0;
           __syncthreads();
           if (lane == 0) {
@@ -513,7 +580,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
   for (int h = 0; h < nh; ++h) {
     const double cnt = humans[h][19], tot = humans[h][18];
     if (cnt < 4.0 || tot / cnt < 0.4) continue;
-    int* kp = w.out_kp + ((size_t)img * OP_MAXH + kept) * 54;
+    int* kp = w.out_kp + ((size_t)img * maxh + kept) * 54;
     if (lane < 18) {
       const double pid = humans[h][lane];
       int x = 0, y = 0, pr = 0;
@@ -521,7 +588,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
         const int id = (int)pid;
         int part = 0;
         while (part < 17 && id >= offs[part + 1]) ++part;
-        const int* yx = w.peak_yx + (((size_t)img * 18 + part) * OP_MAXP + (id - offs[part])) * 2;
+        const int* yx = w.peak_yx + (((size_t)img * 18 + part) * maxp + (id - offs[part])) * 2;
         y = (int)((double)yx[0] / w.scale);
         x = (int)((double)yx[1] / w.scale);
         pr = 1;
@@ -530,7 +597,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const op_work w) {
       kp[lane * 3 + 1] = y;
       kp[lane * 3 + 2] = pr;
     }
-    if (lane == 0) w.out_sc[(size_t)img * OP_MAXH + kept] = tot / cnt;
+    if (lane == 0) w.out_sc[(size_t)img * maxh + kept] = tot / cnt;
     ++kept;
   }
   if (lane == 0) w.out_cnt[img] = over ? 0 : kept;   // a truncated image reports nothing (flagged in w.overflow)
@@ -541,8 +608,8 @@ __global__ __launch_bounds__(256) void op_gather_kernel(const op_work w, int* o_
   int base = 0;
   for (int i = 0; i < img; ++i) base += w.out_cnt[i];
   const int K = w.out_cnt[img];
-  for (int t = threadIdx.x; t < K * 54; t += blockDim.x) o_kp[(size_t)base * 54 + t] = w.out_kp[(size_t)img * OP_MAXH * 54 + t];
-  for (int t = threadIdx.x; t < K; t += blockDim.x) o_sc[base + t] = w.out_sc[(size_t)img * OP_MAXH + t];
+  for (int t = threadIdx.x; t < K * 54; t += blockDim.x) o_kp[(size_t)base * 54 + t] = w.out_kp[(size_t)img * w.maxh * 54 + t];
+  for (int t = threadIdx.x; t < K; t += blockDim.x) o_sc[base + t] = w.out_sc[(size_t)img * w.maxh + t];
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -602,34 +669,183 @@ static int op_upsample_dev(ta_ctx* ctx, const op_maps& m, int N, float* up_out_h
   return TA_OK;
 }
 
+// ---- work areas -------------------------------------------------------------------------------------
+static int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Lays the lists of `N` images out in one device block (base == nullptr: size only).  big: the <BIG> kernels' extra
+// lists (candidates / seen bitmaps / humans in global memory) and the planar map copy; keys come separately (their size
+// is known only after the counting pass of a re-run).
+static size_t layout_work(op_work& w, char* base, int N, bool big, size_t cells) {
+  size_t off = 0;
+  auto carve = [&](size_t b) {
+    char* p = base ? base + off : nullptr;
+    off += rup256(b);
+    return p;
+  };
+  const size_t P = (size_t)w.maxp, H = (size_t)w.maxh;
+  w.peak_cnt = (int*)carve((size_t)N * 18 * 4);
+  w.peak_true = (int*)carve((size_t)N * 18 * 4);
+  w.peak_yx = (int*)carve((size_t)N * 18 * P * 8);
+  w.peak_sc = (float*)carve((size_t)N * 18 * P * 4);
+  w.conn_cnt = (int*)carve((size_t)N * 19 * 4);
+  w.pair_true = (int*)carve((size_t)N * 19 * 4);
+  w.conn_ij = (int*)carve((size_t)N * 19 * P * 8);
+  w.conn_sc = (float*)carve((size_t)N * 19 * P * 4);
+  w.overflow = (int*)carve((size_t)N * 4);
+  w.out_cnt = (int*)carve((size_t)N * 4);
+  w.out_kp = (int*)carve((size_t)N * H * 54 * 4);
+  w.out_sc = (double*)carve((size_t)N * H * 8);
+  if (big) {
+    w.cand_pitch = pow2_at_least(w.maxp);
+    w.planar = (const float*)carve((size_t)N * 57 * cells * 4);
+    w.g_cand = (unsigned long long*)carve((size_t)N * 18 * w.cand_pitch * 8);
+    w.g_seen = (unsigned*)carve((size_t)N * 19 * ((P + 31) / 32) * 4);
+    w.g_humans = (double*)carve((size_t)N * H * 20 * 8);
+  }
+  return off;
+}
+
+static int launch_planar(ta_ctx* ctx, const op_work& w, int N) {
+  const size_t total = (size_t)N * 57 * w.m.h * w.m.w;
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  ta_prof_scope scope(ctx, 3, (double)total * 8);
+  hipLaunchKernelGGL(op_planar_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, w.m, w.img_base, N, (float*)w.planar);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+template <bool BIG>
+static int launch_peaks(ta_ctx* ctx, const op_work& w, int N, size_t lds) {
+  ta_prof_scope scope(ctx, 3, (double)N * 18 * w.m.h * w.m.w * 4);     // algorithmic bytes: the 18 part maps, read once at network resolution
+  if (!BIG) TA_SET_LDS_ATTR(ctx, peaks_kernel<BIG>, 150 * 1024);
+  hipLaunchKernelGGL(peaks_kernel<BIG>, dim3(N * 18), dim3(PK_T), lds, ctx->stream, w);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+template <bool BIG>
+static int launch_limbs(ta_ctx* ctx, const op_work& w, int N, size_t lds) {
+  ta_prof_scope scope(ctx, 3, (double)N * 38 * w.m.h * w.m.w * 4);
+  if (!BIG) TA_SET_LDS_ATTR(ctx, limbs_kernel<BIG>, 150 * 1024);
+  hipLaunchKernelGGL(limbs_kernel<BIG>, dim3(N * 19), dim3(256), lds, ctx->stream, w);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+template <bool BIG>
+static int launch_assemble(ta_ctx* ctx, const op_work& w, int N) {
+  ta_prof_scope scope(ctx, 3, 0.0);
+  hipLaunchKernelGGL(assemble_kernel<BIG>, dim3(N), dim3(64), 0, ctx->stream, w);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
+void ta_pose_free_big(ta_ctx* ctx) {
+  for (auto& o : ctx->pose_dbg.over) (void)hipFree(o.mem);
+  ctx->pose_dbg.over.clear();
+}
+
+// One image that outgrew the fast path's lists (or the <BIG> pass's default ones): the same kernels with every list in
+// global memory, sized from what the passes report -- peaks from the first pass's true counts, candidate pairs from a
+// counting pass of limbs_kernel, humans from the connections kept.  Nothing is capped (wrapper.py:235-262,335-366)
+// beyond 65535 peaks per part (pair indices are 32 bits).
+static int op_rerun_image(ta_ctx* ctx, const op_work& first, int img, const int* peak_true18, std::vector<int32_t>& kp,
+                          std::vector<double>& sc, long long* peaks, long long* conns) {
+  op_work w = first;
+  w.N = 1;
+  w.img_base = first.img_base + img;
+  int maxp = 1;
+  for (int p = 0; p < 18; ++p) maxp = peak_true18[p] > maxp ? peak_true18[p] : maxp;
+  if (maxp > 65535) return ta_fail(ctx, TA_E_OVERFLOW, "openpose: image %d has %d peaks of one part (at most 65535 are supported)", img, maxp);
+  w.maxp = maxp;
+  w.maxc = 1;
+  w.maxh = 1;                                      // out_kp / out_sc / humans of the layout below are placeholders (re-pointed later)
+  const size_t cells = (size_t)w.m.h * w.m.w;
+  const size_t bytes = layout_work(w, nullptr, 1, true, cells);
+  char* mem = nullptr;
+  TA_HIP(ctx, hipMalloc((void**)&mem, bytes));
+  ctx->pose_dbg.over.push_back({img, maxp, mem, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+  layout_work(w, mem, 1, true, cells);
+  TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, 4, ctx->stream));
+  TA_TRY(launch_planar(ctx, w, 1));
+  TA_TRY(launch_peaks<true>(ctx, w, 1, 256));
+  w.g_keys = nullptr;                              // counting pass
+  TA_TRY(launch_limbs<true>(ctx, w, 1, 256));
+  int pairs[19];
+  TA_HIP(ctx, hipMemcpyAsync(pairs, w.pair_true, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int maxc = 1;
+  for (int l = 0; l < 19; ++l) maxc = pairs[l] > maxc ? pairs[l] : maxc;
+  w.maxc = maxc;
+  w.keys_pitch = pow2_at_least(maxc);
+  char* mem2 = nullptr;
+  TA_HIP(ctx, hipMalloc((void**)&mem2, (size_t)19 * w.keys_pitch * 8));
+  struct free_t {
+    char*& p;
+    ~free_t() { if (p) (void)hipFree(p); }
+  } g2{mem2};
+  w.g_keys = (unsigned long long*)mem2;
+  TA_TRY(launch_limbs<true>(ctx, w, 1, 256));
+  int cc[19];
+  TA_HIP(ctx, hipMemcpyAsync(cc, w.conn_cnt, sizeof(cc), hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  long long nconn = 0;
+  for (int l = 0; l < 19; ++l) nconn += cc[l] > 0 ? cc[l] : 0;
+  w.maxh = (int)(nconn + 1);                       // every human is born from a connection
+  const size_t hb = rup256((size_t)w.maxh * 20 * 8), kb = rup256((size_t)w.maxh * 54 * 4), sb = rup256((size_t)w.maxh * 8);
+  char* mem3 = nullptr;
+  TA_HIP(ctx, hipMalloc((void**)&mem3, hb + kb + sb));
+  free_t g3{mem3};
+  w.g_humans = (double*)mem3;
+  w.out_kp = (int*)(mem3 + hb);
+  w.out_sc = (double*)(mem3 + hb + kb);
+  TA_TRY(launch_assemble<true>(ctx, w, 1));
+  int head[2] = {0, 0};
+  TA_HIP(ctx, hipMemcpyAsync(&head[0], w.out_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(&head[1], w.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (head[1]) return ta_fail(ctx, TA_E_OVERFLOW, "openpose: internal error: image %d outgrew lists sized from its own counts", img);
+  kp.resize((size_t)head[0] * 54);
+  sc.resize((size_t)head[0]);
+  if (head[0] > 0) {
+    TA_HIP(ctx, hipMemcpyAsync(kp.data(), w.out_kp, kp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipMemcpyAsync(sc.data(), w.out_sc, sc.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  auto& o = ctx->pose_dbg.over.back();             // debug taps of this image live in `mem` until the next grouping on the context
+  o.peak_cnt = w.peak_cnt;
+  o.peak_yx = w.peak_yx;
+  o.peak_sc = w.peak_sc;
+  o.conn_cnt = w.conn_cnt;
+  o.conn_ij = w.conn_ij;
+  o.conn_sc = w.conn_sc;
+  for (int p = 0; p < 18; ++p) *peaks += peak_true18[p];
+  *conns += nconn;
+  return TA_OK;
+}
+
 // network-resolution maps -> packed results on the host
 static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale, int capacity, int32_t* counts,
                               int32_t* keypoints, double* scores, int32_t* required) {
   const int H8 = m.h * 8, W8 = m.w * 8;
-  size_t off = 0;
-  auto carve = [&](size_t b) {
-    size_t o = off;
-    off += rup256(b);
-    return o;
-  };
-  const size_t o_pcnt = carve((size_t)N * 18 * 4), o_pyx = carve((size_t)N * 18 * OP_MAXP * 8), o_psc = carve((size_t)N * 18 * OP_MAXP * 4);
-  const size_t o_ccnt = carve((size_t)N * 19 * 4), o_cij = carve((size_t)N * 19 * OP_MAXP * 8), o_csc = carve((size_t)N * 19 * OP_MAXP * 4);
-  const size_t o_ovf = carve((size_t)N * 4), o_ocnt = carve((size_t)N * 4), o_okp = carve((size_t)N * OP_MAXH * 54 * 4), o_osc = carve((size_t)N * OP_MAXH * 8);
-  const size_t cap = capacity > 0 ? (size_t)capacity : 0;
-  const size_t o_gkp = carve(cap * 54 * 4), o_gsc = carve(cap * 8);
-  char* scr = nullptr;
-  TA_TRY(ta_scratch(ctx, off, (void**)&scr));
+  ta_pose_free_big(ctx);                                  // re-run areas of the previous grouping (kept for its debug taps)
   if (!ctx->pose_wphase) {                                // constants: uploaded once per context, no per-call copy / sync
     float wp[32];
     phase_weights(wp);
     TA_HIP(ctx, hipMalloc((void**)&ctx->pose_wphase, sizeof(wp)));
     TA_HIP(ctx, hipMemcpy(ctx->pose_wphase, wp, sizeof(wp), hipMemcpyHostToDevice));
   }
-  const size_t map_bytes = (size_t)m.h * m.w * 4;
+  const size_t cells = (size_t)m.h * m.w, map_bytes = cells * 4;
   const size_t lds_peaks = ((map_bytes + 15) & ~(size_t)15) + 128 + (size_t)OP_MAXP * 8;
   const size_t lds_limbs = (size_t)OP_MAXC * 8 + OP_MAXP / 8 + 32 + 128 + 2 * map_bytes;
-  if (lds_peaks > 150 * 1024 || lds_limbs > 150 * 1024)
-    return ta_fail(ctx, TA_E_OVERFLOW, "openpose: %d x %d maps do not fit the grouping kernels' LDS staging", m.h, m.w);
+  // maps beyond the LDS staging (~90 x 160 cells): the whole batch takes the <BIG> kernels (planar float32 copy of the
+  // maps, lists in global memory), at the same list sizes; images that outgrow those are re-run one by one either way
+  const bool big = lds_peaks > 150 * 1024 || lds_limbs > 150 * 1024;
   op_work w;
   memset(&w, 0, sizeof(w));
   w.m = m;
@@ -637,17 +853,19 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   w.N = N;
   w.H8 = H8;
   w.W8 = W8;
-  w.peak_cnt = (int*)(scr + o_pcnt);
-  w.peak_yx = (int*)(scr + o_pyx);
-  w.peak_sc = (float*)(scr + o_psc);
-  w.conn_cnt = (int*)(scr + o_ccnt);
-  w.conn_ij = (int*)(scr + o_cij);
-  w.conn_sc = (float*)(scr + o_csc);
-  w.overflow = (int*)(scr + o_ovf);
   w.scale = scale;
-  w.out_cnt = (int*)(scr + o_ocnt);
-  w.out_kp = (int*)(scr + o_okp);
-  w.out_sc = (double*)(scr + o_osc);
+  w.maxp = OP_MAXP;
+  w.maxc = OP_MAXC;
+  w.maxh = OP_MAXH;
+  w.keys_pitch = OP_MAXC;
+  const size_t cap = capacity > 0 ? (size_t)capacity : 0;
+  const size_t work_bytes = layout_work(w, nullptr, N, big, cells);
+  const size_t keys_bytes = big ? rup256((size_t)N * 19 * OP_MAXC * 8) : 0;
+  const size_t o_gkp = work_bytes + keys_bytes, o_gsc = o_gkp + rup256(cap * 54 * 4);
+  char* scr = nullptr;
+  TA_TRY(ta_scratch(ctx, o_gsc + rup256(cap * 8), (void**)&scr));
+  layout_work(w, scr, N, big, cells);
+  if (big) w.g_keys = (unsigned long long*)(scr + work_bytes);
   TA_HIP(ctx, hipMemsetAsync(w.overflow, 0, (size_t)N * 4, ctx->stream));
   ctx->pose_dbg.n = N;
   ctx->pose_dbg.maxp = OP_MAXP;
@@ -657,57 +875,85 @@ static int op_postprocess_dev(ta_ctx* ctx, const op_maps& m, int N, double scale
   ctx->pose_dbg.conn_cnt = w.conn_cnt;
   ctx->pose_dbg.conn_ij = w.conn_ij;
   ctx->pose_dbg.conn_sc = w.conn_sc;
-  {
-    // algorithmic bytes: the 18 part maps are read once at network resolution
-    ta_prof_scope scope(ctx, 3, (double)N * 18 * m.h * m.w * 4);
-    TA_SET_LDS_ATTR(ctx, peaks_kernel, 150 * 1024);
-    hipLaunchKernelGGL(peaks_kernel, dim3(N * 18), dim3(PK_T), lds_peaks, ctx->stream, w);
-    TA_HIP(ctx, hipGetLastError());
+  if (big) {
+    TA_TRY(launch_planar(ctx, w, N));
+    TA_TRY(launch_peaks<true>(ctx, w, N, 256));
+    TA_TRY(launch_limbs<true>(ctx, w, N, 256));
+    TA_TRY(launch_assemble<true>(ctx, w, N));
+  } else {
+    TA_TRY(launch_peaks<false>(ctx, w, N, lds_peaks));
+    TA_TRY(launch_limbs<false>(ctx, w, N, lds_limbs));
+    TA_TRY(launch_assemble<false>(ctx, w, N));
   }
-  {
-    ta_prof_scope scope(ctx, 3, (double)N * 38 * m.h * m.w * 4);
-    TA_SET_LDS_ATTR(ctx, limbs_kernel, 150 * 1024);
-    hipLaunchKernelGGL(limbs_kernel, dim3(N * 19), dim3(256), lds_limbs, ctx->stream, w);
-    TA_HIP(ctx, hipGetLastError());
-  }
-  {
-    ta_prof_scope scope(ctx, 3, 0.0);
-    hipLaunchKernelGGL(assemble_kernel, dim3(N), dim3(64), 0, ctx->stream, w);
-    TA_HIP(ctx, hipGetLastError());
-  }
-  std::vector<int> ovf(N);
+  std::vector<int> ovf(N), ptrue((size_t)N * 18);
   std::vector<int> stat((size_t)N * 37);           // peaks per (image, part) and connections per (image, limb): statistics only
   TA_HIP(ctx, hipMemcpyAsync(counts, w.out_cnt, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(ovf.data(), w.overflow, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TA_HIP(ctx, hipMemcpyAsync(ptrue.data(), w.peak_true, (size_t)N * 18 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(stat.data(), w.peak_cnt, (size_t)N * 18 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipMemcpyAsync(stat.data() + (size_t)N * 18, w.conn_cnt, (size_t)N * 19 * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->pose_peaks = ctx->pose_connections = 0;
-  for (size_t i = 0; i < (size_t)N * 18; ++i) ctx->pose_peaks += stat[i];
-  for (size_t i = (size_t)N * 18; i < stat.size(); ++i) ctx->pose_connections += stat[i] > 0 ? stat[i] : 0;   // -1 = limb missing
-  long long total = 0;
-  for (int i = 0; i < N; ++i) total += counts[i];          // 0 for an image over a cap
+  long long n_peaks = 0, n_conns = 0;
+  for (int i = 0; i < N; ++i) {
+    if (ovf[i]) continue;                                   // counted by its re-run
+    for (int p = 0; p < 18; ++p) n_peaks += stat[(size_t)i * 18 + p];
+    for (int l = 0; l < 19; ++l) n_conns += stat[(size_t)N * 18 + (size_t)i * 19 + l] > 0 ? stat[(size_t)N * 18 + (size_t)i * 19 + l] : 0;   // -1 = limb missing
+  }
+  // images that outgrew a list: recomputed alone, lists sized from their own counts (their out_cnt above is 0)
+  std::vector<int> over_img;
+  std::vector<std::vector<int32_t>> over_kp;
+  std::vector<std::vector<double>> over_sc;
+  for (int i = 0; i < N; ++i) {
+    if (!ovf[i]) continue;
+    over_img.push_back(i);
+    over_kp.emplace_back();
+    over_sc.emplace_back();
+    TA_TRY(op_rerun_image(ctx, w, i, &ptrue[(size_t)i * 18], over_kp.back(), over_sc.back(), &n_peaks, &n_conns));
+    counts[i] = (int32_t)over_sc.back().size();
+  }
+  ctx->pose_peaks = n_peaks;
+  ctx->pose_connections = n_conns;
+  long long total = 0, fast_total = 0;
+  for (int i = 0; i < N; ++i) {
+    total += counts[i];
+    if (!ovf[i]) fast_total += counts[i];
+  }
   if (required) *required = (int32_t)total;
   if (total > capacity) return ta_fail(ctx, TA_E_CAPACITY, "openpose: %lld humans, capacity %d", total, capacity);
-  if (total > 0) {
+  if (total == 0) return TA_OK;
+  if (over_img.empty()) {
     hipLaunchKernelGGL(op_gather_kernel, dim3(N), dim3(256), 0, ctx->stream, w, (int*)(scr + o_gkp), (double*)(scr + o_gsc));
     TA_HIP(ctx, hipGetLastError());
     TA_HIP(ctx, hipMemcpyAsync(keypoints, scr + o_gkp, (size_t)total * 54 * 4, hipMemcpyDeviceToHost, ctx->stream));
     TA_HIP(ctx, hipMemcpyAsync(scores, scr + o_gsc, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
     TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TA_OK;
   }
-  // an image over a cap does not take the batch down: its count comes back as -1, everything else stands
-  int n_over = 0;
-  for (int i = 0; i < N; ++i)
+  // splice: the fast path's rows (packed in image order, re-run images contribute none there) and the re-run images' rows
+  std::vector<int32_t> fkp((size_t)fast_total * 54);
+  std::vector<double> fsc((size_t)fast_total);
+  if (fast_total > 0) {
+    hipLaunchKernelGGL(op_gather_kernel, dim3(N), dim3(256), 0, ctx->stream, w, (int*)(scr + o_gkp), (double*)(scr + o_gsc));
+    TA_HIP(ctx, hipGetLastError());
+    TA_HIP(ctx, hipMemcpyAsync(fkp.data(), scr + o_gkp, fkp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipMemcpyAsync(fsc.data(), scr + o_gsc, fsc.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  size_t o = 0, fo = 0, k = 0;
+  for (int i = 0; i < N; ++i) {
+    const size_t c = (size_t)counts[i];
     if (ovf[i]) {
-      counts[i] = -1;
-      ++n_over;
+      if (c) {
+        memcpy(keypoints + o * 54, over_kp[k].data(), c * 54 * 4);
+        memcpy(scores + o, over_sc[k].data(), c * 8);
+      }
+      ++k;
+    } else if (c) {
+      memcpy(keypoints + o * 54, fkp.data() + fo * 54, c * 54 * 4);
+      memcpy(scores + o, fsc.data() + fo, c * 8);
+      fo += c;
     }
-  if (n_over) {
-    char msg[200];
-    snprintf(msg, sizeof(msg), "openpose: %d image(s) with more than %d peaks per part, %d candidate pairs per limb or %d humans (count -1)",
-             n_over, OP_MAXP, OP_MAXC, OP_MAXH);
-    ctx->err = msg;
+    o += c;
   }
   return TA_OK;
 }
@@ -812,24 +1058,37 @@ int ta_openpose_debug_read(ta_ctx* ctx, int n, int cap_peaks, int32_t* peak_coun
   if (!ctx || n <= 0 || cap_peaks < 0 || cap_conn < 0) return TA_E_INVALID;
   const auto& d = ctx->pose_dbg;
   if (d.n != n || !d.peak_cnt) return ta_fail(ctx, TA_E_INVALID, "openpose_debug_read: the last grouping on this context had %d images, not %d", d.n, n);
-  const int P = d.maxp;
-  std::vector<int> pc((size_t)n * 18), cc((size_t)n * 19);
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  TA_HIP(ctx, hipMemcpy(pc.data(), d.peak_cnt, pc.size() * 4, hipMemcpyDeviceToHost));
-  TA_HIP(ctx, hipMemcpy(cc.data(), d.conn_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
-  if (peak_counts) memcpy(peak_counts, pc.data(), pc.size() * 4);
-  if (conn_counts) memcpy(conn_counts, cc.data(), cc.size() * 4);
-  for (int i = 0; i < n * 18; ++i) {
-    const int k = pc[i] < cap_peaks ? pc[i] : cap_peaks;
-    if (k <= 0) continue;
-    if (peaks_yx) TA_HIP(ctx, hipMemcpy(peaks_yx + (size_t)i * cap_peaks * 2, d.peak_yx + (size_t)i * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
-    if (peak_scores) TA_HIP(ctx, hipMemcpy(peak_scores + (size_t)i * cap_peaks, d.peak_sc + (size_t)i * P, (size_t)k * 4, hipMemcpyDeviceToHost));
-  }
-  for (int i = 0; i < n * 19; ++i) {
-    const int k = cc[i] < cap_conn ? cc[i] : cap_conn;
-    if (k <= 0) continue;
-    if (conn_ij) TA_HIP(ctx, hipMemcpy(conn_ij + (size_t)i * cap_conn * 2, d.conn_ij + (size_t)i * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
-    if (conn_scores) TA_HIP(ctx, hipMemcpy(conn_scores + (size_t)i * cap_conn, d.conn_sc + (size_t)i * P, (size_t)k * 4, hipMemcpyDeviceToHost));
+  for (int img = 0; img < n; ++img) {
+    // an image that was re-run with larger lists reports from its own work area (local image 0 there)
+    const int *pcnt = d.peak_cnt + (size_t)img * 18, *pyx = d.peak_yx + (size_t)img * 18 * d.maxp * 2;
+    const int *ccnt = d.conn_cnt + (size_t)img * 19, *cij = d.conn_ij + (size_t)img * 19 * d.maxp * 2;
+    const float *psc = d.peak_sc + (size_t)img * 18 * d.maxp, *csc = d.conn_sc + (size_t)img * 19 * d.maxp;
+    int P = d.maxp;
+    for (const auto& o : d.over)
+      if (o.img == img && o.peak_cnt) {
+        pcnt = o.peak_cnt, pyx = o.peak_yx, psc = o.peak_sc, ccnt = o.conn_cnt, cij = o.conn_ij, csc = o.conn_sc;
+        P = o.maxp;
+      }
+    int pc[18], cc[19];
+    TA_HIP(ctx, hipMemcpy(pc, pcnt, sizeof(pc), hipMemcpyDeviceToHost));
+    TA_HIP(ctx, hipMemcpy(cc, ccnt, sizeof(cc), hipMemcpyDeviceToHost));
+    if (peak_counts) memcpy(peak_counts + (size_t)img * 18, pc, sizeof(pc));
+    if (conn_counts) memcpy(conn_counts + (size_t)img * 19, cc, sizeof(cc));
+    for (int p = 0; p < 18; ++p) {
+      const int k = pc[p] < cap_peaks ? pc[p] : cap_peaks;
+      if (k <= 0) continue;
+      const size_t dst = (size_t)img * 18 + p;
+      if (peaks_yx) TA_HIP(ctx, hipMemcpy(peaks_yx + dst * cap_peaks * 2, pyx + (size_t)p * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
+      if (peak_scores) TA_HIP(ctx, hipMemcpy(peak_scores + dst * cap_peaks, psc + (size_t)p * P, (size_t)k * 4, hipMemcpyDeviceToHost));
+    }
+    for (int l = 0; l < 19; ++l) {
+      const int k = cc[l] < cap_conn ? cc[l] : cap_conn;
+      if (k <= 0) continue;
+      const size_t dst = (size_t)img * 19 + l;
+      if (conn_ij) TA_HIP(ctx, hipMemcpy(conn_ij + dst * cap_conn * 2, cij + (size_t)l * P * 2, (size_t)k * 8, hipMemcpyDeviceToHost));
+      if (conn_scores) TA_HIP(ctx, hipMemcpy(conn_scores + dst * cap_conn, csc + (size_t)l * P, (size_t)k * 4, hipMemcpyDeviceToHost));
+    }
   }
   return TA_OK;
 }

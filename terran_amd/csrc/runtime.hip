@@ -152,6 +152,7 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pose_wphase) (void)hipFree(ctx->pose_wphase);
+  ta_pose_free_big(ctx);
   if (ctx->range_flag) (void)hipFree(ctx->range_flag);
   if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
   for (auto& e : ctx->frame_cache) (void)hipFree(e.second);

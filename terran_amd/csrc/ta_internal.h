@@ -111,6 +111,15 @@ struct ta_ctx {
     int n = 0, maxp = 0;
     const int *peak_cnt = nullptr, *peak_yx = nullptr, *conn_cnt = nullptr, *conn_ij = nullptr;
     const float *peak_sc = nullptr, *conn_sc = nullptr;
+    // images of that grouping that were re-run with larger lists (openpose_post.hip: op_rerun_image): their taps live in
+    // `mem`, a device block of their own that stays until the next grouping on the context
+    struct over_t {
+      int img, maxp;
+      void* mem;
+      const int *peak_cnt, *peak_yx, *conn_cnt, *conn_ij;
+      const float *peak_sc, *conn_sc;
+    };
+    std::vector<over_t> over;
   } pose_dbg;
   // conv kernel selection (ta_debug_conv_variant, or TA_CONV_PREFER for tools): 0 = automatic, else the TA_CV_* variant
   // every conv that variant CAN run is launched on (others stay automatic);
@@ -123,6 +132,7 @@ struct ta_ctx {
   int* range_flag = nullptr;
   int* range_flag_host = nullptr;
 };
+void ta_pose_free_big(ta_ctx* ctx);  // frees pose_dbg.over
 int ta_range_enqueue(ta_ctx* ctx);   // async copy of the flag on the context's stream (before the call's final sync)
 int ta_range_check(ta_ctx* ctx);     // after that sync: TA_OK, or TA_E_RANGE (and the flag is cleared for the next call)
 

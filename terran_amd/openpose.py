@@ -7,9 +7,9 @@ from . import lib, pack, runtime
 
 
 class PoseOverflow(RuntimeError):
-    """An image went over a grouping cap of the device kernels (1024 peaks per part / 8192 candidate pairs per limb /
-    192 people; the reference has no such limits).  The other images of the batch are not lost: `results` is the full
-    per-image list with `None` at the positions in `images`."""
+    """Kept for callers that catch it: the library no longer caps the grouping lists (an image that outgrows the LDS
+    fast path is recomputed with lists in global memory, include/terran_amd.h: ta_openpose_run), so a per-image count
+    of -1 -- what this exception reported, `results` holding `None` at the positions in `images` -- cannot come back."""
 
     def __init__(self, message, results, images):
         super().__init__(message)

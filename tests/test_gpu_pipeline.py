@@ -237,23 +237,47 @@ def test_openpose_group_vs_oracle_exact(ctx):
     assert z == [[]]
 
 
-def test_openpose_cap_overflow_keeps_the_other_images(ctx):
-    """An image over a grouping cap (here 1153 peaks of one part on a flat plateau; the device list holds 1024) is
-    reported per image: PoseOverflow carries the other images' results (== oracle), and the context stays usable."""
+def test_openpose_lists_grow_beyond_the_fast_path(ctx):
+    """The reference has no caps (wrapper.py:235-262,335-366).  The device's fast path keeps 1024 peaks per part, 8192
+    candidate pairs per limb and 192 people in LDS; an image that outgrows them is re-run alone with lists in global
+    memory sized from its own counts.  Image 1 here carries exact plateaus of two connected parts (1153 peaks each ->
+    ~6.6e5 accepted candidate pairs of limb neck -> nose, 1153 two-part people under assembly): every stage must equal
+    the oracle's, and the other images of the batch go through the fast path untouched."""
     from oracle import openpose_post
     from terran_amd import openpose
     hm, paf = synth.pose_maps_batch(5, 3, 3, 20, 28)
-    hm[1, 0, 5:12, 6:14] = 0.5                      # exact plateau: every x8 pixel inside passes the >= test
-    with pytest.raises(openpose.PoseOverflow) as e:
-        openpose.group(ctx, paf, hm, 1.0)
-    assert e.value.images == [1] and e.value.results[1] is None and '1024' in str(e.value)
-    ref = openpose_post.postprocess(paf[[0, 2]], hm[[0, 2]], 1.0)
-    for got, want in zip([e.value.results[0], e.value.results[2]], ref):
-        assert len(got) == len(want) > 0
-        for a, b in zip(got, want):
+    hm[1, 0, 5:12, 6:14] = 0.5                      # exact plateaus: every x8 pixel inside passes the >= test
+    hm[1, 1, 5:12, 6:14] = 0.5
+    cx, cy = openpose_post.MAP_IDX[12][0] - 19, openpose_post.MAP_IDX[12][1] - 19     # limb 12 = neck -> nose
+    paf[1, cx], paf[1, cy] = 1.0, 0.0               # uniform field along +x: every pair with dx > 0.05 |d| is accepted
+    ref = openpose_post.postprocess(paf, hm, 1.0)
+    got = openpose.group(ctx, paf, hm, 1.0)
+    assert [len(g) for g in got] == [len(r) for r in ref] and len(ref[0]) > 0 and len(ref[2]) > 0
+    for gp, rp in zip(got, ref):
+        for a, b in zip(gp, rp):
             assert np.array_equal(a['keypoints'], b['keypoints']) and a['score'] == b['score']
+    peaks, conns = ctx.pose_debug(3, cap_peaks=2048, cap_conn=2048)
+    n0, n1, n12 = len(peaks[1][0][1]), len(peaks[1][1][1]), len(conns[1][12][1])
+    assert n0 > 1024 and n1 > 1024 and n12 > 192, (n0, n1, n12)          # beyond the fast path's lists
+    _assert_stage_taps_equal(ctx, 3, hm, paf, caps=2048)
+    assert ctx.pose_stats()[0] >= n0 + n1
+    # the context stays usable, and the fast path is back for an ordinary batch
     again = openpose.group(ctx, paf[:1], hm[:1], 1.0)
     assert len(again[0]) == len(ref[0])
+
+
+def test_openpose_large_maps_take_the_global_memory_kernels(ctx):
+    """Maps too large for the grouping kernels' LDS staging (1080p at native resolution: 135 x 240 cells) run on the
+    same kernels reading a planar copy of the maps from global memory: == oracle."""
+    from oracle import openpose_post
+    from terran_amd import openpose
+    hm, paf = synth.pose_maps_batch(77, 2, 6, 135, 240)
+    ref = openpose_post.postprocess(paf, hm, 0.5, 'torch')
+    got = openpose.group(ctx, paf, hm, 0.5)
+    assert [len(g) for g in got] == [len(r) for r in ref] and sum(len(r) for r in ref) >= 6
+    for gp, rp in zip(got, ref):
+        for a, b in zip(gp, rp):
+            assert np.array_equal(a['keypoints'], b['keypoints']) and a['score'] == b['score']
 
 
 def test_openpose_call_vs_oracle(pose, states):
@@ -274,10 +298,10 @@ def _flat(poses):
     return [len(p) for p in poses], kp, sc
 
 
-def _assert_stage_taps_equal(ctx, n, hm, paf, scale=1.0):
+def _assert_stage_taps_equal(ctx, n, hm, paf, scale=1.0, caps=1024):
     """Device peaks / connections of the LAST grouping on `ctx` == the oracle's on the same network-resolution maps."""
     from oracle import openpose_post
-    peaks, conns = ctx.pose_debug(n)
+    peaks, conns = ctx.pose_debug(n, cap_peaks=caps, cap_conn=caps)
     hm_up, paf_up = openpose_post.bicubic_x8(hm), openpose_post.bicubic_x8(paf)
     n_peaks = n_conn = 0
     for i in range(n):
@@ -547,16 +571,32 @@ def test_retinaface_many_candidates_global_sort_and_thresholds(ctx):
             assert np.array_equal(a['bbox'], b['bbox']) and a['score'] == b['score']
 
 
-def test_openpose_overflow_is_an_error_not_a_hang(ctx):
-    """A flat heat-map makes every interior pixel a peak (>= against equal neighbours): the per-part limit must
-    surface as an error (PoseOverflow naming the image), never as silent truncation or a hang."""
+def test_estimation_short_side_736_runs_on_the_large_map_path(states):
+    """`Estimation(short_side=736)` on a 16:9 frame: 92 x 163 network-resolution maps, beyond the grouping kernels' LDS
+    staging (round 2 failed this call with TA_E_OVERFLOW; the reference has no such limit, openpose/wrapper.py:93-113).
+    People assemble and equal the oracle's."""
+    from oracle import pipeline
+    from terran_amd import Estimation
+    sd = states('openpose_decoder')
+    frame = synth.pose_code_frames(91, 1, 736, 1304, 5)[0]
+    est = Estimation(device=0, short_side=736, state=sd)
+    got = est(frame)
+    ref = pipeline.estimation(sd, frame, short_side=736, bicubic_impl='torch')
+    assert len(got) == len(ref) >= 4
+    for a, b in zip(got, ref):
+        assert np.array_equal(a['keypoints'], b['keypoints'])
+        np.testing.assert_allclose(a['score'], b['score'], rtol=2e-4)
+
+
+def test_openpose_saturated_heatmap_runs_to_completion(ctx):
+    """A flat heat-map makes every interior pixel of every part a peak (>= against equal neighbours): 11 844 peaks per
+    part, 1.4e8 candidate pairs per limb.  The reference would grind through it; so does the device (lists in global
+    memory), and with zero PAFs nobody assembles."""
     from terran_amd import openpose
     hm = np.full((1, 19, 12, 16), 0.5, np.float32)
     paf = np.zeros((1, 38, 12, 16), np.float32)
-    with pytest.raises(openpose.PoseOverflow) as e:
-        openpose.group(ctx, paf, hm, 1.0)
-    assert e.value.images == [0] and e.value.results == [None]
-    # and the context is still usable afterwards
+    assert openpose.group(ctx, paf, hm, 1.0) == [[]]
+    assert ctx.pose_stats() == (18 * 94 * 126, 0)
     g = openpose.group(ctx, np.zeros((1, 38, 6, 8), np.float32), np.zeros((1, 19, 6, 8), np.float32), 1.0)
     assert g == [[]]
 
