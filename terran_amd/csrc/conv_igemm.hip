@@ -1555,10 +1555,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     const int img = pix / HoWo;
     const int rem = pix - img * HoWo;
     const int y = rem / p.Wo, x = rem - y * p.Wo;
+    if (p.res) {                                     // the same order as the one-pass epilogues: activation, + shortcut, store, second output
+      const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
+      const f32x4 r = ta_ld4(p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0, p.res_ch + co, p.res_fmt);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
     ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, p.out_ch + co,
            p.out_fmt, v);
-    if (p.prec == PREC_F16X3 && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) <= TA_F16_MAX))
-      *p.range_flag = 1;
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (p.out2) {
+      const f32x4 sc = *(const f32x4*)(p.scale2 + co), sh = *(const f32x4*)(p.shift2 + co);
+      f32x4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = v[e] * sc[e] + sh[e];
+      ta_st4(p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0, p.o2_ch + co, p.o2_fmt, z);
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
+    }
+    if (p.prec == PREC_F16X3 && !(amax <= TA_F16_MAX)) *p.range_flag = 1;
   }
 }
 

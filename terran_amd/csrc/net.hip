@@ -21,7 +21,7 @@ static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad -
 static bool conv_ksplit_eligible(const ta_op_desc& op, int in_fmt) {
   const bool uniform = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
   const bool kernel_ok = in_fmt == ta_split_fmt_of(op.prec);
-  return uniform && kernel_ok && op.res < 0 && op.out2 < 0 && op.groups <= 1;
+  return uniform && kernel_ok && op.groups <= 1 && !op.pool;
 }
 
 #define TA_MAX_PLANS 4
@@ -212,7 +212,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
     const ta_op_desc& op = m->ops[oi];
     if (op.type != TA_OP_CONV) continue;
     const int M = ts[op.out].n * ts[op.out].h * ts[op.out].w;
-    const int ks = ta_conv_ksplit(op.coutp, op.n_slabs, conv_ksplit_eligible(op, ts[op.in].fmt));
+    const int ks = ta_conv_ksplit(op.coutp, op.n_slabs, conv_ksplit_eligible(op, ts[op.in].fmt), (op.variant >> 8) & 255);
     if (ks > 1) ws_bytes = std::max(ws_bytes, (size_t)ks * M * op.coutp * sizeof(float));
   }
   const size_t ws_off = total;
@@ -374,7 +374,7 @@ int ta_model_run_ops(ta_model* m) {
           p.group_cout = op.cout / op.groups;
           p.group_cin = op.cin;
         }
-        p.variant = op.variant;
+        p.variant = op.variant & 255;
         p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
@@ -383,7 +383,7 @@ int ta_model_run_ops(ta_model* m) {
           flops = 2.0 * op.macs_per_pixel * (double)m->run_n * conv_out(ti.h, op.kh, op.stride, op.pad) *
                   conv_out(ti.w, op.kw, op.stride, op.pad);   // algorithmic: the whole conv output, odd edge included
         }
-        p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt)) : 1;
+        p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt), (op.variant >> 8) & 255) : 1;
         p.partial = m->splitk_ws;
         TA_TRY(ta_launch_conv(ctx, p, flops));
         break;

@@ -60,7 +60,8 @@ struct ta_op_desc {
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
   int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
-  int32_t variant;                    // 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests)
+  int32_t variant;                    // bits 0..7: 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests);
+                                      // bits 8..15: K-split factor fixed by the packer for this layer (0 = the library's rule)
   int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
   int32_t wscale_log2;                // f16x3: the packed weights are W * 2^wscale_log2 (their lo halves stay normal half floats);
                                       // the epilogue multiplies the sums by 2^-wscale_log2 (exact).  0 in the other modes
@@ -264,8 +265,12 @@ static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32
 // the batch -- the summation order, and with it every output bit, must not change with the batch composition
 // (sharding a batch over GPUs has to reproduce the unsharded result exactly).  Shared by the planner (workspace size)
 // and the launcher.  1 = no split.
-static inline int ta_conv_ksplit(int coutp, int n_slabs, bool eligible) {
-  if (!eligible || coutp % 128 || n_slabs < 512) return 1;
+// `packed` = the factor the packer wrote for the op (ta_op_desc.variant bits 8..15; 0 = none): layers whose output is
+// too small to fill the chip at any batch in use (ArcFace stage 4: 7 x 7 maps, 100 tiles at 64 crops) get a fixed 2.
+static inline int ta_conv_ksplit(int coutp, int n_slabs, bool eligible, int packed = 0) {
+  if (!eligible || coutp % 128) return 1;
+  if (packed > 1) return packed <= n_slabs ? packed : 1;
+  if (n_slabs < 512) return 1;
   return 32;
 }
 

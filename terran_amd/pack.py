@@ -128,7 +128,7 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None, groups=1, variant=0, pool=False):
+             scale2=None, shift2=None, groups=1, variant=0, pool=False, k_split=0):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
         ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
         groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
@@ -136,6 +136,8 @@ class Program:
         of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups).
         variant != 0 pins the conv to one kernel variant (lib.CONV_VARIANTS; parity tests): loading fails when that
         kernel cannot run the layer.
+        k_split > 1: the layer's K is cut in that many fixed ranges (one workgroup each, ordered reduction): for layers whose
+        output is too small to fill the chip at any batch in use.  A property of the LAYER, never of the batch.
         pool=True fuses the 2x2 / 2 max-pool that follows the conv (+ activation) into its epilogue: `tout` is the POOLED
         tensor (split-role kernel only: cin % 32 == 0, cout % 64 == 0, plain epilogue)."""
         W = np.asarray(W, dtype=np.float64)
@@ -175,7 +177,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
-                  groups=groups, variant=variant, pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, variant=variant | (int(k_split) << 8), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -473,7 +475,9 @@ def pack_arcface(sd, precision='f32'):
         s, sh = _bn_affine(sd, p + '.body.2', eps)
         W1, b1 = _fold(sd[p + '.body.1.weight'], None, s, sh)
         Y = P.tensor(cout, 1)
-        P.conv(Z, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'])
+        # stage 4 (7 x 7 maps, 512 channels): 100 output tiles at 64 crops on 256 CUs, 144 K slabs -> K in two fixed halves
+        ks = 2 if (cout == 512 and not os.environ.get('TERRAN_AMD_NO_STAGE4_KSPLIT')) else 0
+        P.conv(Z, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'], k_split=ks if cin == 512 else 0)
         if sc:
             s, sh = _bn_affine(sd, p + '.shortcut.1', eps)
             Ws, bs = _fold(sd[p + '.shortcut.0.weight'], None, s, sh)
@@ -488,7 +492,7 @@ def pack_arcface(sd, precision='f32'):
         Rn = P.tensor(cout, 0)
         Zn = P.tensor(cout, 0 if last else 1)
         s2, sh2 = next_bn(i + 1)
-        P.conv(Y, Rn, W2, b2, stride=stride, res=res, out2=Zn, scale2=s2, shift2=sh2)
+        P.conv(Y, Rn, W2, b2, stride=stride, res=res, out2=Zn, scale2=s2, shift2=sh2, k_split=ks)
         if u == arch.ARC_UNITS[st] - 1:
             P.tap('stage%d' % (st + 1), Rn, 0, cout)
         R, Z = Rn, Zn
@@ -520,8 +524,11 @@ def pack_retinaface(sd, precision='f32', fused=None):
     # order of near-tied scores in 3 % of the images.  The graph is HBM-bound (35 FLOP/B), so the exact-f32 MFMA costs
     # next to nothing here: in the `bf16x3` mode the detector runs on it, and its results ARE the `f32` mode's, bit for
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
-    P = Program(MODEL_RETINAFACE, 'f32' if precision in ('bf16x3', 'f16x3') else precision)
-    P.allow_split = False
+    det_prec = 'f32' if precision in ('bf16x3', 'f16x3') else precision
+    if precision == 'f16x3' and os.environ.get('TERRAN_AMD_DETECTOR_F16X3'):      # experiment: the detector's convs on the split-half MFMA too
+        det_prec = 'f16x3'
+    P = Program(MODEL_RETINAFACE, det_prec)
+    P.allow_split = bool(os.environ.get('TERRAN_AMD_DETECTOR_SPLIT'))
     if fused is None:
         fused = P.prec == 0 and not os.environ.get('TERRAN_AMD_NO_FUSED_DETECTOR')       # A/B switch
     tin = P.tensor(4, 1, alias_of=-2 if fused else -1, name='input')
