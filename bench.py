@@ -30,8 +30,9 @@ float32-grade results: tests/test_gpu_decisions_vs_oracle.py -- frames resident 
   per_model                     BASELINE configs C2 (RetinaFace 32x640x640), C3 (ArcFace 256 crops), C4 (OpenPose
                                 16x368x656), each with its own roofline (N = 1 only)
   roofline / cpu_baseline       see README / DESIGN.md section 5
-`python bench.py --gpus N --single-process` (no torchrun) drives N devices from ONE process through the facades'
-device-list fan-out (facade._Fanout) instead of one process per GPU.
+`python bench.py --gpus N --single-process` (no torchrun) drives N devices from ONE process through
+terran_amd.pipeline.StreamPipeline (per device: lanes of upload / detect -> embed / pose threads) instead of one process
+per GPU; `--devices 0,0` puts two replicas on one card.
 """
 import argparse
 import io
@@ -746,48 +747,87 @@ def per_model(ctx, precisions, reps=8):
 
 
 def run_single_process(args):
-    """--single-process: ONE process, one host thread + context + weights per device (facade device lists), host
-    frames scattered as contiguous sub-batches and results gathered in order (SURVEY.md 8e as specified)."""
-    from terran_amd import Detection, Recognition, Estimation, lib, runtime
+    """--single-process: ONE process drives all devices through terran_amd.pipeline.StreamPipeline -- per device
+    `--inflight` lanes of (upload, detect -> embed, pose) threads with a context each, frames sharded contiguously over
+    the devices, results gathered in frame order (SURVEY.md 8e as specified).  Two legs: `value` with the shards resident
+    in HBM (the per-process headline's condition) and `ingest` with every batch scattered from host memory inside the
+    timed region."""
+    from terran_amd import runtime
+    from terran_amd.pipeline import StreamPipeline
     devices = [int(d) for d in args.devices.split(',')] if args.devices else list(range(args.gpus))
     n = len(devices)
     (sd_r, sd_a, sd_p), one, fallback_lm = make_workload(args, 0)
     frames_host = np.concatenate([one] * n) if n > 1 else one          # B frames per device per step
     prec = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or 'f16x3')
-    det = Detection(short_side=416, device=devices, state=sd_r, precision=prec)
-    rec = Recognition(device=devices, state=sd_a, precision=prec)
-    est = Estimation(short_side=184, device=devices, state=sd_p, precision=prec)
     F = args.faces
+    sys.setswitchinterval(float(os.environ.get('TA_BENCH_SWITCH', '2e-4')))
 
-    from concurrent.futures import ThreadPoolExecutor
-    side = ThreadPoolExecutor(max_workers=1)
+    def pick(dets):
+        return [[{'landmarks': x['landmarks']} for x in d[:F]] + [{'landmarks': fallback_lm[k]} for k in range(len(d[:F]), F)]
+                for d in dets]
+    L = max(1, args.inflight)
+    pipe = StreamPipeline(devices, inflight=L, pick_faces=pick,
+                          detection_kw=dict(short_side=416, state=sd_r, precision=prec),
+                          recognition_kw=dict(state=sd_a, precision=prec),
+                          estimation_kw=dict(short_side=184, state=sd_p, precision=prec))
+    resident = pipe.scatter(frames_host)
 
-    def step():
-        fr = det.upload(frames_host)                      # scatter: ONE upload per device, shared by the three facades
-        try:
-            pose_f = side.submit(est, fr)                  # pose runs beside detect -> embed (own contexts / streams)
-            dets = det(fr)
-            faces = [[{'landmarks': x['landmarks']} for x in d[:F]] +
-                     [{'landmarks': fallback_lm[k]} for k in range(len(d[:F]), F)] for d in dets]
-            return dets, rec(fr, faces), pose_f.result()
-        finally:
+    def timed(batches, k):
+        t0 = time.perf_counter()
+        out, got = None, 0
+        for out in pipe.run(batches):
+            got += 1
+        assert got == k
+        return time.perf_counter() - t0, out
+    warm = max(args.warmup, 2 * L)
+    timed((resident for _ in range(warm)), warm)
+    elapsed, out = timed((resident for _ in range(args.steps)), args.steps)
+    # one batch alone with a HIP event pair around every launch of lane 0 of device 0 -> the per-class times of a step
+    lane = pipe.lanes[0][0]
+    ctxs = [lane.det.model.ctx, lane.rec.model.ctx, lane.est.model.ctx]
+    for c in ctxs:
+        c.profile_reset()
+        c.profile(True)
+    timed(([resident[0]] + [None] * (n - 1) for _ in range(1)), 1)
+    klass = {}
+    for k_, name in enumerate(KLASSES):
+        ms = cnt = work = 0
+        for c in ctxs:
+            a_, b_, w_ = c.profile_read(k_)
+            ms, cnt, work = ms + a_, cnt + b_, work + w_
+        klass[name] = {'ms': round(ms, 3), 'launches': cnt, 'work': work}
+    for c in ctxs:
+        c.profile(False)
+    k_in = max(2 * L, min(args.steps, 60))
+    timed((frames_host for _ in range(2 * L)), 2 * L)
+    e_in, _ = timed((frames_host for _ in range(k_in)), k_in)
+    for fr in resident:
+        if fr is not None:
             fr.free()
-    for _ in range(max(1, args.warmup)):
-        out = step()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    elapsed = time.perf_counter() - t0
+    pipe.close()
+    per_step = elapsed / args.steps
+    roof = conv_roofline(prec, klass['conv_igemm'])
+    work_step = klass['conv_igemm']['work'] * n                    # every device does one device-0 share per step
+    roof['pipelined_achieved'] = round(work_step / per_step / 1e12, 2)
+    roof['pipelined_frac'] = round(work_step / per_step / 1e12 / (PEAKS[prec][0] * len(set(devices))), 4)
     return {
         'metric': 'frames/sec 1080p detect+embed+pose', 'value': round(len(frames_host) * args.steps / elapsed, 3),
-        'unit': 'frames/s', 'n_gpus': len(set(devices)), 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'unit': 'frames/s', 'n_gpus': len(set(devices)), 'steps': args.steps, 'warmup': warm,
+        'ms_per_step': round(per_step * 1e3, 3), 'timed_region_s': round(elapsed, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': DTYPES[prec], 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[4], single process: %d device replicas %s, %d host frames per replica per '
-                               'step scattered from one host array (one PCIe upload per device inside the timed region, shared by the three '
-                               'facades), pose beside detect -> embed, ordered gather' % (n, devices, args.batch),
+        'config': {'workload': 'BASELINE configs[4], ONE process: %d device replica(s) %s x %d lanes of upload / detect -> embed / pose '
+                               'threads (terran_amd.pipeline.StreamPipeline), %d frames per replica per step, shards resident in HBM, '
+                               'results gathered in frame order on the calling thread' % (n, devices, L, args.batch),
                    'precision': prec, 'frames_per_step': len(frames_host), 'faces_per_frame': F,
-                   'humans_per_frame': round(float(np.mean([len(p) for p in out[2]])), 2)}}
+                   'detections_per_frame': round(float(np.mean([len(d) for d in out[0]])), 1),
+                   'humans_per_frame': round(float(np.mean([len(p) for p in out[2]])), 2)},
+        'roofline': roof,
+        'stage_ms_per_step': {k_: v['ms'] for k_, v in klass.items()},
+        'ingest': {'value': round(len(frames_host) * k_in / e_in, 3), 'unit': 'frames/s', 'steps': k_in,
+                   'ms_per_step': round(e_in / k_in * 1e3, 3), 'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
+                   'what': 'the same loop fed from host memory: every batch is cut into contiguous shards, each uploaded by its '
+                           "lane's upload thread on its own stream (scatter), results gathered in order (gather), all inside the timed region"},
+        'value_ingest': round(len(frames_host) * k_in / e_in, 3)}
 
 
 def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):

@@ -1,11 +1,21 @@
 """Process-wide device contexts and weight resolution for the wrapper classes."""
+import collections
 import os
+import threading
 
 import numpy as np
 
 from . import lib, weights
 
 _contexts = {}
+_pack_memo = collections.OrderedDict()
+_memo_lock = threading.Lock()
+
+
+def clear_pack_memo():
+    """Drop the packed programs kept for dict states (they pin the state dicts and a few hundred MB of blobs)."""
+    with _memo_lock:
+        _pack_memo.clear()
 
 
 def device_index(device):
@@ -98,7 +108,22 @@ def packed_program(kind, state, precision):
     elif isinstance(state, (str, os.PathLike)):
         path = state
     if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE'):
-        return packer(resolve_state(kind, state), precision)
+        # dict states (tests, bench, StreamPipeline's lanes): many models of one process are built from the SAME dict --
+        # pack it once (a pack is seconds of numpy work; 16 lanes x 3 networks would spend a minute on it)
+        sd = resolve_state(kind, state)
+        key = (kind, id(sd), precision, tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('TERRAN_AMD_'))))   # + pack-time switches
+        with _memo_lock:
+            hit = _pack_memo.get(key)
+            if hit is not None and hit[0] is sd:
+                _pack_memo.move_to_end(key)
+                return hit[1]
+        prog = packer(sd, precision)
+        prog._blob = prog.blob()                    # built once, shared by every model loaded from it
+        with _memo_lock:
+            _pack_memo[key] = (sd, prog)            # holds `sd`: its id cannot be recycled while the entry lives
+            while len(_pack_memo) > 6:
+                _pack_memo.popitem(last=False)
+        return prog
     st = os.stat(path)
     cache = '%s.%s.%d.%d.v%d.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime),
                                      pack.BLOB_VERSION)
