@@ -110,7 +110,7 @@ class LoopStream(io.RawIOBase):
     delivers, terran/io/video/reader.py:421-465): readinto() is one host memcpy out of the batch, like a pipe read."""
 
     def __init__(self, batch, n_batches):
-        self.buf = memoryview(np.ascontiguousarray(batch).reshape(-1))
+        self.buf = np.ascontiguousarray(batch).reshape(-1)
         self.left = len(self.buf) * n_batches
         self.pos = 0
 
@@ -121,7 +121,9 @@ class LoopStream(io.RawIOBase):
         n = min(len(b), self.left, len(self.buf) - self.pos)
         if n <= 0:
             return 0
-        b[:n] = self.buf[self.pos:self.pos + n]
+        # numpy copies release the GIL (a memoryview slice assignment does not, and would stall every launch thread of the
+        # process for the ~25 ms a 199 MB batch takes): like the read() system call behind a real pipe
+        np.copyto(np.frombuffer(b, dtype=np.uint8, count=n), self.buf[self.pos:self.pos + n])
         self.pos = (self.pos + n) % len(self.buf)
         self.left -= n
         return n
@@ -140,7 +142,7 @@ def main():
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or f16x3)')
     ap.add_argument('--single-mode', action='store_true',
                     help='headline measurement only (no f32 / faces-per-frame / sustained / ingest / per-model legs)')
-    ap.add_argument('--inflight', type=int, default=2, help='batches in flight per GPU (pipelines of 3 streams each)')
+    ap.add_argument('--inflight', type=int, default=4, help='lanes per GPU: batches in flight, each on its own upload / detect / embed / pose streams')
     ap.add_argument('--serial', action='store_true',
                     help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
                          'rocprofv3 kernel statistics under profiles/ are taken in, so that their per-kernel averages '
@@ -369,11 +371,21 @@ def run(args):
             for f in self.frames:
                 f.free()
 
-    pipes = [Pipeline(i == 0) for i in range(L)]
+    # The timed regions run on the product's own engine, terran_amd.pipeline.StreamPipeline over this rank's device: L
+    # lanes of (upload, detect -> embed, pose) threads with a context each.  The class above stays for the one-kernel-at-
+    # a-time modes (--serial / --join-steps) and for the event-profiled serial step the roofline figures come from.
+    from terran_amd.pipeline import StreamPipeline
+    streaming = not (args.serial or args.join_steps)
+    pipes = [Pipeline(True)]
+    engine = {}
 
     def sync():
         for p in pipes:
             p.sync()
+        if engine.get('sp') is not None:
+            for lane in engine['sp'].lanes[0]:
+                for c in (lane.ctx_up, lane.det.model.ctx, lane.rec.model.ctx, lane.est.model.ctx):
+                    c.sync()
         if use_dist:
             if backend == 'nccl':
                 torch.cuda.synchronize()
@@ -389,9 +401,18 @@ def run(args):
             for _ in range(k):
                 res = pipes[0].start(1)()
             return res
-        joins = [p.start(len(range(i, k, L)), readers[i] if readers else None, on_step) for i, p in enumerate(pipes)]
-        outs = [j() for j in joins]
-        return next(o for o in outs if o is not None)
+        sp = engine['sp']
+        if readers:                                   # every step takes a fresh batch a reader thread uploaded; freed after use
+            batches = ([next(readers[i % len(readers)])] for i in range(k))
+        else:
+            batches = (engine['resident'] for _ in range(k))
+        out, got = None, 0
+        for out in sp.run(batches, free_resident=bool(readers)):
+            got += 1
+            if on_step:
+                on_step(*out)
+        assert got == k                               # every step produced its detections, embeddings and poses
+        return out
 
     def timed(k, **kw):
         sync()
@@ -408,6 +429,9 @@ def run(args):
     def profile_serial_step():
         """One serial step with a HIP event pair around every launch (per-kernel-class time and algorithmic work)."""
         p0 = pipes[0]
+        if streaming:                                 # the timed region ran on the lanes: these three models are still cold
+            for _ in range(2):                        # (plans, result-capacity retry of the first detector call)
+                p0.serial_step()
         for c in p0.ctxs:
             c.profile_reset()
             c.profile(True)
@@ -428,12 +452,22 @@ def run(args):
         extra(result_dict): further legs measured while this mode's models are loaded."""
         for p in pipes:
             p.load(precision)
+        if streaming:
+            engine['sp'] = StreamPipeline([device_index], inflight=L, pick_faces=pick_faces,
+                                          detection_kw=dict(short_side=416, state=sd_r, precision=precision),
+                                          recognition_kw=dict(state=sd_a, precision=precision),
+                                          estimation_kw=dict(short_side=184, state=sd_p, precision=precision))
+            engine['resident'] = engine['sp'].scatter(frames_host)            # resident in HBM before timing
         if args.warmup:
-            run_steps(args.warmup if args.serial else max(args.warmup, L))      # every pipeline warms its plans
+            run_steps(args.warmup if not streaming else max(args.warmup, 2 * L))      # every lane warms its plans
         elapsed, out = timed(steps)
         res = {'elapsed': elapsed, 'out': out, 'klass': profile_serial_step()}
         if extra:
             extra(res)
+        if streaming:
+            for fr in engine['resident']:
+                fr.free()
+            engine.pop('sp').close()
         for p in pipes:
             p.unload()
         return res
@@ -477,8 +511,9 @@ def run(args):
         def on_step(dets, feats, poses):                 # called per finished step (pipelines finish out of order
             with lock:                                    # relative to each other; every pipeline's own steps are in order)
                 gathered.append(pack_step(dets, feats, poses) if use_dist else (dets, feats, poses))
-        readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, L))), W, H,
-                                        batch_size=args.batch, device=device_index) for i in range(L)]
+        R = L                                                        # reader threads (pinned double buffers + upload stream each; a stream read is a single-thread ~30 ms memcpy)
+        readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, R))), W, H,
+                                        batch_size=args.batch, device=device_index) for i in range(R)]
         n_on_rank0 = [0]
 
         def gather_all():
@@ -490,7 +525,7 @@ def run(args):
             else:
                 n_on_rank0[0] = len(gathered)
         try:
-            run_steps(2 * L, readers=readers)                                        # warm the readers' buffers
+            run_steps(2 * L, readers=readers)                                        # warm the readers' buffers (2 batches each)
             del gathered[:]
             sync()
             t0 = time.perf_counter()
@@ -571,13 +606,14 @@ def run(args):
                 'pose_peaks_per_frame': round(pipes[0].ctxs[2].pose_stats()[0] / float(args.batch), 1),
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
-                'streams_per_gpu': 3 * L,
+                'streams_per_gpu': 4 * L,
                 'batches_in_flight_per_gpu': L,
                 'step_overlap': 'serial: one kernel at a time' if args.serial else
                                 'one step at a time' if args.join_steps else
-                                '%d pipeline(s) of detect / embed / pose host threads, pipeline p takes steps p, p+%d, '
-                                '... (embed consumes the detections of its batch through a queue); joined once at '
-                                'the end of the timed region' % (L, L),
+                                'terran_amd.pipeline.StreamPipeline: %d lanes of upload / detect -> embed / pose host threads '
+                                '(a context = HIP stream each), lane l takes steps l, l+%d, ... (embed consumes the detections '
+                                'of its batch through a queue), results collected in step order; the region ends when the '
+                                'last step is collected' % (L, L),
             },
             'roofline': dict(conv_roofline(primary, klass['conv_igemm']),
                              # the same algorithmic FLOPs over the PIPELINED step (what `value` is made of): above the serial

@@ -58,10 +58,10 @@ class _Lane:
                 for q in (self.q_det, self.q_rec, self.q_est):
                     q.put(_STOP)
                 return
-            key, shard, pick = job
+            key, shard, pick, free_resident = job
             own = not isinstance(shard, lib.Frames)
             frames = self.ctx_up.upload(shard) if own else shard
-            refs = [3, threading.Lock(), frames if own else None]   # freed by whichever task finishes with it last
+            refs = [3, threading.Lock(), frames if (own or free_resident) else None]   # freed by whichever task finishes with it last
             for q in (self.q_det, self.q_rec, self.q_est):
                 q.put((key, frames, refs, pick))
 
@@ -105,6 +105,21 @@ class _Lane:
             key, frames, refs, _ = job
             self.out_q.put((key, 2, self.est(frames)))
             self._release(refs)
+
+
+    def close(self):
+        """After the threads have stopped: release device memory NOW (models, plans, scratch, streams) rather than whenever
+        the garbage collector finds the objects -- a late hipFree waits for every stream of the process, i.e. it would stall
+        whatever pipeline is running by then."""
+        for facade in (self.det, self.rec, self.est):
+            wrapper = facade.model
+            if wrapper is None:
+                continue
+            for m in (getattr(wrapper, 'model', None), getattr(wrapper, '_fb_model', None)):
+                if m is not None:
+                    m.free()
+        for c in (self.det.model.ctx, self.rec.model.ctx, self.est.model.ctx, self.ctx_up):
+            c.close()
 
 
 def all_faces(dets):
@@ -154,9 +169,11 @@ class StreamPipeline:
             out.append(self.lanes[r][0].ctx_up.upload(images[lo:hi]) if hi > lo else None)
         return out
 
-    def run(self, batches):
+    def run(self, batches, free_resident=False):
         """Generator: one (detections, features, poses) triple per batch, in batch order; lists over the batch's frames.
-        A batch is a host array / list of equally sized frames, or what `scatter` returned (resident shards, not freed)."""
+        A batch is a host array / list of equally sized frames, or a list with one resident `lib.Frames` (or None) per
+        device -- what `scatter` returned, or batches a `video.RawVideoReader` uploaded; those are left alone unless
+        free_resident (the pipeline then frees each one when its three tasks are through with it)."""
         k = len(self.devices)
         pending = {}                       # batch -> {(device, kind): result}
         n_shards = {}
@@ -180,7 +197,7 @@ class StreamPipeline:
                     fed[0] = b + 1
                     for r, s in enumerate(shards):
                         if s is not None:
-                            self.lanes[r][b % self.inflight].in_q.put(((b, r), s, self.pick_faces))
+                            self.lanes[r][b % self.inflight].in_q.put(((b, r), s, self.pick_faces, free_resident))
                     if n_shards[b] == 0:
                         self._out.put(((b, -1), 3, None))           # an empty batch still yields its (empty) triple
             except BaseException as e:                              # noqa: BLE001
@@ -216,3 +233,6 @@ class StreamPipeline:
             for lane in lanes:
                 for t in lane.threads:
                     t.join(timeout=30)
+                if not any(t.is_alive() for t in lane.threads):
+                    lane.close()
+        self.lanes = []
