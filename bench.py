@@ -626,6 +626,16 @@ def run(args):
             'stage_hbm_gbps': {k: round(v['work'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in klass.items()
                                if k != 'conv_igemm' and v['ms'] > 0},
         }
+        if args.serial:
+            # --serial is the mode the rocprofv3 kernel statistics under profiles/ are taken in: the algorithmic FLOPs every
+            # dense-conv kernel INSTANCE did over this whole run (warm-up, timed and event-profiled steps), so that the
+            # profiler's per-kernel time table turns into TFLOP/s per template instance (profiles/summarize_round.py)
+            work = {}
+            for c in pipes[0].ctxs:
+                for name, (n_, fl) in c.kernel_work().items():
+                    a_, b_ = work.get(name, (0, 0.0))
+                    work[name] = (a_ + n_, b_ + fl)
+            result['kernel_work_run'] = {k_: {'launches': v[0], 'gflop': round(v[1] / 1e9, 2)} for k_, v in sorted(work.items())}
         if 'f32' in others:                                          # the like-for-like reference arithmetic, top level
             result['value_f32'] = others['f32']['value']
             result['ms_per_step_f32'] = others['f32']['ms_per_step']

@@ -17,6 +17,6 @@ for P in f16x3 f32; do
 done
 # the pipelined headline under a kernel trace: how much of the timed region has 0 / 1 / 2 / 3+ kernels in flight
 timeout 600 rocprofv3 --kernel-trace -d $O/kt_pipelined -o k -- python $R/bench.py --steps 60 --warmup 6 --no-cpu-baseline --single-mode > $O/kt_pipelined.log 2>&1
-timeout 120 python $R/tools/busy_fraction.py $O/kt_pipelined/k_results.db 0.1 0.88 > $O/pipelined_busy.txt 2>&1
+timeout 120 python $R/tools/busy_fraction.py $O/kt_pipelined/k_results.db > $O/pipelined_busy.txt 2>&1
 timeout 600 python $R/profiles/summarize_round.py $O $O/summary 2>&1 | tail -40
 ls $O | head -40

@@ -1,6 +1,6 @@
 """Summaries of one profiles/collect.sh run (rocprofv3 rocpd sqlite outputs under <collect dir>):
     python profiles/summarize_round.py gpurun_out/collect profiles/r02
-writes, per precision P in {bf16x3, f32}:
+writes, per precision P in {f16x3, f32}:
   <prefix>_<P>_kernel_stats.csv     per-kernel totals of the --kernel-trace --stats run (bench.py --serial)
   <prefix>_<P>_top_dispatches.csv   the 60 longest dispatches (grid, LDS, VGPRs, duration)
   <prefix>_pmc_conv_<P>.json        HBM bytes of the conv kernels (FETCH_SIZE x2 + WRITE_SIZE, separate passes; the x2 is
@@ -23,14 +23,27 @@ def find_db(d):
     return c[0] if c else None
 
 
-def kernel_tables(db_path, prefix):
+def _norm(name):
+    """'void conv_igemm_split<2, 4, 4, 3, 3>(ta_conv_launch)' -> 'conv_igemm_split<2,4,4,3,3>' (the library's own naming)."""
+    n = name.replace('void ', '').split('(')[0].replace(' ', '')
+    return n
+
+
+def kernel_tables(db_path, prefix, work=None):
+    """work: {kernel instance: {'launches', 'gflop'}} of the same run (bench.py --serial prints it as `kernel_work_run`):
+    adds the algorithmic GFLOP and TFLOP/s of every dense-conv template instance to the table."""
     cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
+    unit_us = 1e3 if max(r[2] for r in rows) > 1e6 else 1.0           # rocpd's top_kernels view: ns (older) or us
     with open(prefix + '_kernel_stats.csv', 'w', newline='') as f:
         w = csv.writer(f)
-        w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'pct'])
+        w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'pct', 'algorithmic_gflop', 'tflops'])
         for name, calls, total, avg, pct in rows:
-            w.writerow([name, calls, round(total / 1e3, 3) if total > 1e6 else round(total, 3), round(avg, 3), round(pct, 3)])   # ns -> us
+            total_us = total / unit_us
+            wk = (work or {}).get(_norm(name))
+            gf = wk['gflop'] if wk else ''
+            tf = round(wk['gflop'] / 1e3 / (total_us * 1e-6), 1) if wk and total_us > 0 else ''
+            w.writerow([name, calls, round(total_us, 3), round(avg, 3), round(pct, 3), gf, tf])
     disp = list(cur.execute('select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, '
                             '(end-start) from kernels order by (end-start) desc limit 60'))
     with open(prefix + '_top_dispatches.csv', 'w', newline='') as f:
@@ -56,11 +69,18 @@ def pmc_total(db_path, counter):
 
 
 def main(collect, prefix, steps=3):
-    for P in ('bf16x3', 'f32'):
+    for P in ('f16x3', 'f32'):
         kt = find_db(os.path.join(collect, 'kt_' + P))
         out = {}
         if kt:
-            out['kernel_trace'] = kernel_tables(kt, '%s_%s' % (prefix, P))
+            work = None
+            try:                                                    # the bench line of the traced run (stdout of kt_<P>.log)
+                for line in open(os.path.join(collect, 'kt_%s.log' % P)):
+                    if line.startswith('{') and 'kernel_work_run' in line:
+                        work = json.loads(line)['kernel_work_run']
+            except (OSError, ValueError):
+                pass
+            out['kernel_trace'] = kernel_tables(kt, '%s_%s' % (prefix, P), work)
         pm = {}
         for C in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             db = find_db(os.path.join(collect, 'pmc_%s_%s' % (C, P)))

@@ -22,6 +22,7 @@
 //   channels of one pixel per accumulator quad -> 16-byte NHWC stores, fused bias / ReLU /
 //   PReLU / residual (optionally nearest-x2 upsampled) / second affine output.
 #include <stdlib.h>
+#include <string.h>
 
 #include "act_format.h"
 #include "ta_internal.h"
@@ -1607,6 +1608,11 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
   }
   static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
   q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
+  {
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "conv_igemm_split<%d,%d,%d,%d,%d>", CM, CN, NP, PREC, STAGES);
+    ctx->note_kernel(name);
+  }
   hipLaunchKernelGGL(kern, dim3(groups * 8 * p.k_split), dim3(64 * (CM * CN + NP)), lds_bytes, ctx->stream, q);
   TA_HIP(ctx, hipGetLastError());
   if (p.k_split > 1) {
@@ -1626,6 +1632,11 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC>;
+  {
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC);
+    ctx->note_kernel(name);
+  }
   TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
@@ -1641,6 +1652,11 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = (size_t)STAGES * (BN + BM) * 32 * sizeof(float);
   auto kern = conv_igemm_pipe<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES, BSPLIT>;
+  {
+    static char name[80];
+    if (!name[0]) snprintf(name, sizeof(name), "conv_igemm_pipe<%d,%d,%d,%d,%d,%d,%s>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, STAGES, BSPLIT ? "true" : "false");
+    ctx->note_kernel(name);
+  }
   TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
@@ -1656,6 +1672,11 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
   auto kern = conv_dwpw<WAVES_M, WAVES_N, WM_TILES, WN_TILES>;
+  {
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "conv_dwpw<%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES);
+    ctx->note_kernel(name);
+  }
   TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
   hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
   TA_HIP(ctx, hipGetLastError());
@@ -1671,6 +1692,7 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
       p.n_slabs * 32 < p.dw_c)
     return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 mode, float32 activations and 4-aligned channels");
   ta_prof_scope scope(ctx, 0, flops);
+  ctx->cur_flops = flops;
   if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2>(ctx, p);
   if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1>(ctx, p);
   return launch_dwpw_cfg<1, 4, 1, 1>(ctx, p);
@@ -1769,6 +1791,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
     p.direct_epilogue = 0;
   }                                              // only the split-role kernel knows K ranges
   ctx->conv_counts[v] += 1;
+  ctx->cur_flops = flops;
   ta_prof_scope scope(ctx, 0, flops);
   switch (p.prec) {
     case PREC_F32: return launch_variant<PREC_F32>(ctx, v, p);
@@ -1783,6 +1806,20 @@ extern "C" {
 int ta_debug_conv_variant(ta_ctx* ctx, int variant) {
   if (!ctx || variant < 0 || variant >= TA_CV_COUNT) return TA_E_INVALID;
   ctx->conv_force = variant;
+  return TA_OK;
+}
+
+int ta_debug_kernel_work(ta_ctx* ctx, char* csv, size_t capacity, int reset) {
+  if (!ctx || (!csv && capacity)) return TA_E_INVALID;
+  std::string out;
+  for (const auto& kv : ctx->kernel_work) {
+    char line[160];
+    snprintf(line, sizeof(line), "%s;%lld;%.6e\n", kv.first.c_str(), (long long)kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (reset) ctx->kernel_work.clear();
+  if (out.size() + 1 > capacity) return ta_fail(ctx, TA_E_CAPACITY, "kernel_work: %zu bytes needed", out.size() + 1);
+  memcpy(csv, out.c_str(), out.size() + 1);
   return TA_OK;
 }
 

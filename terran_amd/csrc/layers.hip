@@ -283,6 +283,8 @@ int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w
     return ta_fail(ctx, TA_E_INVALID, "rfstem: destination tensor mismatch");
   if (n <= 0) return TA_OK;
   ta_prof_scope scope(ctx, 0, 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w);   // the two dense convs (depthwise MACs are not counted anywhere)
+  ctx->cur_flops = 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w;
+  ctx->note_kernel("rf_stem_kernel");
   rf_stem_weights wt;                                                   // 1.8 KB of kernel arguments
   memcpy(wt.v, weights_host, sizeof(wt.v));
   hipLaunchKernelGGL(rf_stem_kernel, dim3((out.w + RFS_T - 1) / RFS_T, (out.h + RFS_T - 1) / RFS_T, n), dim3(256), 0, ctx->stream,

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -132,6 +133,15 @@ struct ta_ctx {
   // the pinned host word behind the results of a call (ta_range_enqueue) and turned into TA_E_RANGE (ta_range_check)
   int* range_flag = nullptr;
   int* range_flag_host = nullptr;
+  // algorithmic FLOPs per dense-conv KERNEL INSTANCE ("conv_igemm_split<2,4,4,3,3>", ...) since the last reset
+  // (ta_debug_kernel_work): joins a rocprofv3 per-kernel time table with the work each template instance did
+  double cur_flops = 0;
+  std::map<std::string, std::pair<int64_t, double>> kernel_work;
+  void note_kernel(const char* name) {
+    auto& e = kernel_work[name];
+    e.first += 1;
+    e.second += cur_flops;
+  }
 };
 void ta_pose_free_big(ta_ctx* ctx);  // frees pose_dbg.over
 int ta_range_enqueue(ta_ctx* ctx);   // async copy of the flag on the context's stream (before the call's final sync)

@@ -49,7 +49,8 @@ class ShardedFrames:
 
     def __init__(self, parts, bounds, n):
         self.parts, self.bounds, self.n = parts, bounds, n
-        self.shape = (n,) + tuple(parts[0].shape[1:]) if parts else (0, 0, 0, 3)
+        first = next((p for p in parts if p is not None), None)        # replicas beyond the batch size hold no part
+        self.shape = (n,) + tuple(first.shape[1:]) if first is not None else (n, 0, 0, 3)
 
     def __len__(self):
         return self.n
@@ -258,6 +259,8 @@ class Recognition:
         if faces_per_image is not None and len(faces_per_image) != len(images):
             raise ValueError('`images` and `faces_per_image` must be of the same size, but the former is of size '
                              '%d while the latter of size %d.' % (len(images), len(faces_per_image)))
+        if self._fanout is not None and faces_per_image is None and isinstance(images, ShardedFrames):
+            raise ValueError('a scattered frame batch needs `faces_per_image` (pre-cropped faces go in as a host list)')
         if self._fanout is not None and faces_per_image is not None:
             out = self._fanout(images if isinstance(images, ShardedFrames) else list(images), list(faces_per_image))
             if any(len(f) for f in faces_per_image):                    # a shard without faces answers float64 (0,512)

@@ -73,6 +73,7 @@ SIGNATURES = {
     'ta_debug_conv_variant': (c_int, [c_void_p, c_int]),
     'ta_debug_range_check': (c_int, [c_void_p]),
     'ta_debug_conv_counts': (c_int, [c_void_p, c_void_p, c_int]),
+    'ta_debug_kernel_work': (c_int, [c_void_p, C.c_char_p, c_size_t, c_int]),
 }
 
 # conv kernel variants (include/terran_amd.h TA_CONV_*)
@@ -214,6 +215,16 @@ class Context:
         out = {k: int(c[v]) for k, v in CONV_VARIANTS.items() if v and c[v]}
         if c[15]:
             out['lean_epilogue'] = int(c[15])          # split-role launches that ran the specialised drain
+        return out
+
+    def kernel_work(self, reset=False):
+        """{kernel instance name: (launches, algorithmic FLOPs)} of the dense-conv kernels since the last reset."""
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.ta_debug_kernel_work(self.h, buf, len(buf), int(reset)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, fl = line.split(';')
+            out[name] = (int(n), float(fl))
         return out
 
     def pose_debug(self, n, cap_peaks=1024, cap_conn=1024):
