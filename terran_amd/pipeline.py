@@ -50,6 +50,13 @@ class _Lane:
             fn()
         except BaseException as e:                              # noqa: BLE001  (re-raised in the consumer)
             self.fail(e)
+            for q in (self.q_det, self.q_rec, self.q_est, self.q_faces):     # a lane that lost a thread stops as a whole
+                q.put(_STOP)
+            while True:                                         # ... and lets go of what is still queued for it
+                try:
+                    self.in_q.get_nowait()
+                except queue.Empty:
+                    break
 
     def _upload(self):
         while True:
@@ -228,7 +235,10 @@ class StreamPipeline:
     def close(self):
         for lanes in self.lanes:
             for lane in lanes:
-                lane.in_q.put(_STOP)
+                try:
+                    lane.in_q.put(_STOP, timeout=5)
+                except queue.Full:                              # its upload thread is gone: the task threads were told already
+                    pass
         for lanes in self.lanes:
             for lane in lanes:
                 for t in lane.threads:

@@ -261,6 +261,21 @@ def main():
     save('facade_recognition.npz', one=one, lst=lst1, many0=many[0], many1=many[1],
          many1_dtype=str(many[1].dtype), note='reference Recognition rank handling on arcface_call.npz image')
 
+    # the reference's own tables, straight from its modules: state_dict keys + shapes of the three networks (default
+    # constructors) and the limb tables of the pose wrapper.  terran_amd/arch.py (which the packer AND the oracle walk)
+    # is compared with these, so a shared table error cannot hide behind oracle == product agreement.
+    def keys_shapes(module):
+        sd = module.state_dict()
+        names = [k for k in sd if not k.endswith('num_batches_tracked')]
+        return np.array(names), np.array([list(sd[k].shape) + [0] * (4 - sd[k].dim()) for k in names], np.int64)
+    rk, rs = keys_shapes(RM.RetinaFace())
+    ak, as_ = keys_shapes(AM.FaceResNet100())
+    pk, ps = keys_shapes(PM.BodyPoseModel())
+    save('arch_tables.npz', retinaface_keys=rk, retinaface_shapes=rs, arcface_keys=ak, arcface_shapes=as_,
+         openpose_keys=pk, openpose_shapes=ps, map_idx=np.array(PW.map_idx, np.int64), limbseq=np.array(PW.limbseq, np.int64),
+         note='reference modules (default constructors): state_dict keys / shapes (padded to 4 dims with 0) and '
+              'pose/openpose/wrapper.py:12-24 map_idx / limbseq')
+
 
 if __name__ == '__main__':
     main()
