@@ -67,7 +67,7 @@ def main():
                 bad += 1
                 print('FAIL', prec, case)
                 print('   ', ''.join(traceback.format_exception_only(type(e), e)).strip()[:600])
-    print('%d cases x 2 precisions, %d failures' % (n, bad))
+    print('%d cases x 3 precisions, %d failures' % (n, bad))
     return 1 if bad else 0
 
 
