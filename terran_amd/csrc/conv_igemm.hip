@@ -227,6 +227,42 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
   if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
 }
 
+// ---- LDS-staged epilogue of the symmetric-wave kernels (conv_igemm, conv_igemm_pipe, conv_dwpw) ---------------------
+// The direct epilogue above stores straight from the accumulators: a store instruction scatters 16 B to 32 different
+// pixels (32 cache lines per instruction).  Like the split-role kernel, these kernels now park the raw tile in the LDS ring
+// they are done with -- [pixel][cout], 16-byte chunks XOR-swizzled with the pixel row -- and drain it with one lane per
+// (pixel, 8 consecutive channels), whole 128-byte lines per instruction, through the same conv_epilogue_drain.  Same
+// arithmetic in the same order (fma(acc, unscale, bias), activation, shortcut, second output): same bits.
+template <int BN, int BM, int NT>
+__device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid,
+                                                    int HoWo, int ks);
+
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__device__ __forceinline__ void conv_finish_sym(const ta_conv_launch& p, f32x16 (&acc)[WM_TILES][WN_TILES], float* lds, int ct0,
+                                                int pt0, int wm, int wn, int tid, int lane, int HoWo) {
+  constexpr int BN = WAVES_M * WM_TILES * 32, BM = WAVES_N * WN_TILES * 32, NCH = BN / 4;
+  const bool staged = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
+  if (!staged) {
+    conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+    return;
+  }
+  __syncthreads();                                  // every wave is done reading operand fragments: the ring is free
+#pragma unroll
+  for (int b = 0; b < WN_TILES; ++b) {
+    const int row = (wn * WN_TILES + b) * 32 + (lane & 31);
+#pragma unroll
+    for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = ((wm * WM_TILES + a) * 32 + 8 * j + 4 * (lane >> 5)) >> 2;
+        *(f32x4*)(lds + (row * NCH + (c ^ (row & (NCH - 1)))) * 4) =
+            f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+      }
+  }
+  __syncthreads();
+  conv_epilogue_drain<BN, BM, 256>(p, lds, ct0, pt0, tid, HoWo, 0);
+}
+
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;   // output channels per workgroup
@@ -395,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
     }
   }
 
-  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+  conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
 
 // K-slab order of the uniform-K kernels (conv_igemm_pipe, conv_igemm_split): channel block OUTERMOST, then ky, then kx.
@@ -694,7 +730,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     mma(X);
   }
 
-  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+  conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
 
 
@@ -834,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
     }
   }
-  conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+  conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
 
 // t / d for a launch-uniform divisor whose float32 reciprocal the launcher supplied: one multiply and a +-1 fix-up
