@@ -62,7 +62,7 @@ HBM_PEAK_GBPS = 8000.0
 DTYPES = {'f32': 'f32',
           'f16x3': 'f16x3 (ArcFace / OpenPose operands x = hi + lo as two IEEE half floats = 22 significant bits, weights '
                    'pre-scaled by a power of two per layer; 3 f16 MFMAs per product term (every product exact), f32 '
-                   'accumulate; the detector RetinaFace runs on the exact-f32 MFMA) -- float32-grade: 0 decision flips vs '
+                   'accumulate; the detector RetinaFace: refiner + deep base the same, the raw-pixel front exact f32) -- float32-grade: 0 decision flips vs '
                    'the oracle over 224 frames per task where the exact-f32 mode has 2 (profiles/r03_decisions_vs_oracle.txt)',
           'bf16x3': 'bf16x3 (ArcFace / OpenPose operands x = hi + lo as two bf16, ~16 mantissa bits; 3 bf16 MFMAs per '
                     'product term, f32 accumulate; the detector RetinaFace runs on the exact-f32 MFMA) -- passes the '

@@ -263,6 +263,76 @@ __device__ __forceinline__ void conv_finish_sym(const ta_conv_launch& p, f32x16 
   conv_epilogue_drain<BN, BM, 256>(p, lds, ct0, pt0, tid, HoWo, 0);
 }
 
+// One K slab (32) of a symmetric-wave tile: A fragments from the packed weight rows, B fragments from float32 pixel rows
+// (split into 16-bit hi / lo words in registers in the split modes).  Shared by conv_igemm and conv_dwpw.
+template <int WM_TILES, int WN_TILES, int PREC>
+__device__ __forceinline__ void conv_slab_mma(const float* st, f32x16 (&acc)[WM_TILES][WN_TILES], int a_row0, int b_row0, int fsw,
+                                              int fcb, int lane) {
+  if constexpr (PREC == PREC_F32) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int pc = ((fcb + g) ^ fsw) * 4;
+      f32x4 av[WM_TILES], bv[WN_TILES];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
+#pragma unroll
+      for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int b = 0; b < WN_TILES; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+    }
+  } else {
+    // K-step t covers k = 16*kgrp + 8t + (0..7): weight chunk 2*kgrp+t (hi) / 4+2*kgrp+t (lo),
+    // activation float chunks kgrp*4 + 2t and kgrp*4 + 2t + 1.
+    const int kg = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a) {
+        ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+        if constexpr (prec_x3(PREC)) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      }
+#pragma unroll
+      for (int b = 0; b < WN_TILES; ++b) {
+        const f32x4 x0 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
+        const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 h0 = ta_to16<PREC>(x0[e]), h1 = ta_to16<PREC>(x1[e]);
+          bh[b][e] = h0;
+          bh[b][4 + e] = h1;
+          if constexpr (prec_x3(PREC)) {
+            bl[b][e] = ta_to16<PREC>(x0[e] - ta_from16<PREC>(h0));
+            bl[b][4 + e] = ta_to16<PREC>(x1[e] - ta_from16<PREC>(h1));
+          }
+        }
+      }
+      if constexpr (prec_x3(PREC)) {
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int b = 0; b < WN_TILES; ++b)
+            acc[a][b] = ta_mfma16<PREC>(al[a], bh[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int b = 0; b < WN_TILES; ++b)
+            acc[a][b] = ta_mfma16<PREC>(ah[a], bl[b], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b)
+          acc[a][b] = ta_mfma16<PREC>(ah[a], bh[b], acc[a][b]);
+    }
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;   // output channels per workgroup
@@ -366,69 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
       if (s + 2 < S) kt_next = p.ktab[(s + 2) * 8 + lchunk];
     }
     const float* st = lds + (s & 1) * STAGE;
-    if constexpr (PREC == PREC_F32) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int pc = ((fcb + g) ^ fsw) * 4;
-        f32x4 av[WM_TILES], bv[WN_TILES];
-#pragma unroll
-        for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
-#pragma unroll
-        for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-            for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
-      }
-    } else {
-      // K-step t covers k = 16*kgrp + 8t + (0..7): weight chunk 2*kgrp+t (hi) / 4+2*kgrp+t (lo),
-      // activation float chunks kgrp*4 + 2t and kgrp*4 + 2t + 1.
-      const int kg = lane >> 5;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
-#pragma unroll
-        for (int a = 0; a < WM_TILES; ++a) {
-          ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-          if constexpr (prec_x3(PREC)) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
-        }
-#pragma unroll
-        for (int b = 0; b < WN_TILES; ++b) {
-          const f32x4 x0 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t) ^ fsw) * 4);
-          const f32x4 x1 = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + ((fcb + 2 * t + 1) ^ fsw) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const __bf16 h0 = ta_to16<PREC>(x0[e]), h1 = ta_to16<PREC>(x1[e]);
-            bh[b][e] = h0;
-            bh[b][4 + e] = h1;
-            if constexpr (prec_x3(PREC)) {
-              bl[b][e] = ta_to16<PREC>(x0[e] - ta_from16<PREC>(h0));
-              bl[b][4 + e] = ta_to16<PREC>(x1[e] - ta_from16<PREC>(h1));
-            }
-          }
-        }
-        if constexpr (prec_x3(PREC)) {
-#pragma unroll
-          for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-            for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = ta_mfma16<PREC>(al[a], bh[b], acc[a][b]);
-#pragma unroll
-          for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-            for (int b = 0; b < WN_TILES; ++b)
-              acc[a][b] = ta_mfma16<PREC>(ah[a], bl[b], acc[a][b]);
-        }
-#pragma unroll
-        for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-          for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = ta_mfma16<PREC>(ah[a], bh[b], acc[a][b]);
-      }
-    }
+    conv_slab_mma<WM_TILES, WN_TILES, PREC>(st, acc, a_row0, b_row0, fsw, fcb, lane);
   }
 
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
@@ -739,9 +747,9 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 // (retinaface/model.py:26-39, 60-99) regrouped as [dw_k -> pw_{k+1}].  The graph is HBM-bound (35 FLOP/B): the
 // depthwise output never leaves the CU.  Same tile machinery as conv_igemm above (weights DMA'd per K slab, fragments,
 // epilogue), but the pixel rows of a slab are COMPUTED into LDS -- 9 taps x 16-byte loads per (pixel, 4 channels), fmaf
-// chain in (ky, kx) order exactly like dwconv3x3_kernel -- instead of DMA'd.  Exact-f32 MFMA only (the detector runs
-// on it in both parity modes).
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+// chain in (ky, kx) order exactly like dwconv3x3_kernel -- instead of DMA'd.  The 1x1 runs on the exact-f32 MFMA, or
+// (PREC_F16X3: pack.dwpw(precision='f16x3')) on the split-half MFMA with the float32 depthwise rows split in registers.
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC = PREC_F32>
 __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   // Measured alternatives (32 x 416 x 739 frames, 12 blocks): this symmetric 4-wave kernel, two workgroups per CU,
   // 541 us; 8 waves with the tap loads of slab s+1 issued ahead of the MFMAs of slab s (208 VGPRs, one workgroup per CU,
@@ -853,22 +861,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
     __syncthreads();   // slab s (weights landed, pixel rows written); everyone is done reading the other stage
     if (s + 1 < S) produce(s + 1, (s + 1) & 1);
     const float* st = lds + (s & 1) * STAGE;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int pc = ((fcb + g) ^ fsw) * 4;
-      f32x4 av[WM_TILES], bv[WN_TILES];
-#pragma unroll
-      for (int a = 0; a < WM_TILES; ++a) av[a] = *(const f32x4*)(st + (a_row0 + a * 32) * 32 + pc);
-#pragma unroll
-      for (int b = 0; b < WN_TILES; ++b) bv[b] = *(const f32x4*)(st + (b_row0 + b * 32) * 32 + pc);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int a = 0; a < WM_TILES; ++a)
-#pragma unroll
-          for (int b = 0; b < WN_TILES; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
-    }
+    conv_slab_mma<WM_TILES, WN_TILES, PREC>(st, acc, a_row0, b_row0, fsw, fcb, lane);
   }
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
@@ -1699,7 +1692,7 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   return TA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
   constexpr int BM = WAVES_N * WN_TILES * 32;
@@ -1707,10 +1700,10 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
-  auto kern = conv_dwpw<WAVES_M, WAVES_N, WM_TILES, WN_TILES>;
+  auto kern = conv_dwpw<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC>;
   {
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "conv_dwpw<%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES);
+    if (!name[0]) snprintf(name, sizeof(name), "conv_dwpw<%d,%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC);
     ctx->note_kernel(name);
   }
   TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
@@ -1722,16 +1715,21 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
 int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p_in.M <= 0) return TA_OK;
   ta_conv_launch p = p_in;
-  p.w_unscale = 1.f;
+  if (!(p.w_unscale > 0.f)) p.w_unscale = 1.f;
   p.range_flag = ctx->range_flag;
-  if (p.prec != PREC_F32 || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w || !p.dw_bias ||
-      p.n_slabs * 32 < p.dw_c)
-    return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 mode, float32 activations and 4-aligned channels");
+  if ((p.prec != PREC_F32 && p.prec != PREC_F16X3) || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w ||
+      !p.dw_bias || p.n_slabs * 32 < p.dw_c)
+    return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 or f16x3 mode, float32 input activations and 4-aligned channels");
   ta_prof_scope scope(ctx, 0, flops);
   ctx->cur_flops = flops;
-  if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2>(ctx, p);
-  if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1>(ctx, p);
-  return launch_dwpw_cfg<1, 4, 1, 1>(ctx, p);
+  if (p.prec == PREC_F16X3) {
+    if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
+    if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F16X3>(ctx, p);
+    return launch_dwpw_cfg<1, 4, 1, 1, PREC_F16X3>(ctx, p);
+  }
+  if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F32>(ctx, p);
+  if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F32>(ctx, p);
+  return launch_dwpw_cfg<1, 4, 1, 1, PREC_F32>(ctx, p);
 }
 
 // ---- kernel selection ---------------------------------------------------------------------------------------------

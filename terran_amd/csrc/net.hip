@@ -411,6 +411,7 @@ int ta_model_run_ops(ta_model* m) {
         p.act = op.act;
         p.stride = 1;
         p.prec = op.prec;
+        p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;
         p.in_pix = ti.c;
@@ -503,6 +504,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
       bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
     } else if (op.type == TA_OP_DWPW) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.scale2_off < 0 || op.shift2_off < 0 || op.cin % 4 || op.cout % 4 ||
+            (op.prec != 0 && op.prec != 3) || (op.prec != 3 && op.wscale_log2 != 0) ||
             op.coutp % 32 || op.n_slabs <= 0 || op.n_slabs * 32 < op.cin || (op.stride != 1 && op.stride != 2) ||
             bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) || bad_w(op.bias_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.cin * 36) || bad_w(op.shift2_off, (size_t)op.cin * 4);

@@ -323,10 +323,14 @@ int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, flo
     return TA_OK;
   }
   TA_TRY(ta_model_forward_frames(m, frames));
+  TA_TRY(ta_range_enqueue(ctx));                 // behind the network, ahead of the post-processing's syncs
   ta_tensor heads[3];
   for (int l = 0; l < 3; ++l) heads[l] = m->tensors[m->hdr.outputs[l]];
-  return rf_postprocess_dev(ctx, heads, frames->n, frames->h, frames->w, 0, score_thr, nms_thr, capacity, counts, boxes,
-                            landmarks, scores, required);
+  const int rc = rf_postprocess_dev(ctx, heads, frames->n, frames->h, frames->w, 0, score_thr, nms_thr, capacity, counts, boxes,
+                                    landmarks, scores, required);
+  if (rc != TA_OK && rc != TA_E_CAPACITY) return rc;
+  const int rr = ta_range_check(ctx);            // f16x3 layers: TA_E_RANGE when an activation left the half-float range
+  return rr != TA_OK ? rr : rc;
 }
 
 int ta_retinaface_postprocess(ta_ctx* ctx, const float* const heads[9], int n, int h, int w, float score_thr,

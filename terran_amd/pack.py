@@ -128,7 +128,7 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None, groups=1, variant=0, pool=False, k_split=0):
+             scale2=None, shift2=None, groups=1, variant=0, pool=False, k_split=0, precision=None):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
         ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
         groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
@@ -163,9 +163,10 @@ class Program:
         flat[:K] = full.reshape(K, coutp)
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
         wscale = 0
-        if self.prec == 3:
+        prec = self.prec if precision is None else PRECISIONS[precision]      # a single op may run in another arithmetic mode
+        if prec == 3:
             packed, wscale = split_f16_rows(packed)
-        elif self.prec != 0:
+        elif prec != 0:
             packed = split_bf16_rows(np.ascontiguousarray(packed))
 
         def vec(v):
@@ -176,7 +177,7 @@ class Program:
             return self._w(out)
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
-                  res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=self.prec,
+                  res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
                   groups=groups, variant=variant | (int(k_split) << 8), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
@@ -207,10 +208,12 @@ class Program:
         op['in'] = tin
         self.ops.append(op)
 
-    def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1):
+    def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1, precision=None):
         """Depthwise 3x3 (stride 1 / 2, pad 1) + ReLU fused into the following 1x1 conv + ReLU (both BN-folded):
-        Wd (C,1,3,3) / bd (C,), Wp (cout, C, 1, 1) / bp (cout,).  Exact-f32 MFMA only."""
-        assert self.prec == 0, 'the fused depthwise + pointwise block exists in the f32 mode only'
+        Wd (C,1,3,3) / bd (C,), Wp (cout, C, 1, 1) / bp (cout,).  The depthwise part is float32 FMAs; the 1x1 runs on the
+        exact-f32 MFMA or (precision='f16x3') on the split-half MFMA."""
+        prec = self.prec if precision is None else PRECISIONS[precision]
+        assert prec in (0, 3), 'the fused depthwise + pointwise block exists in the f32 and f16x3 modes'
         C = Wd.shape[0]
         Wp = np.asarray(Wp, np.float64)
         cout = Wp.shape[0]
@@ -220,12 +223,15 @@ class Program:
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:C, :cout] = Wp.reshape(cout, C).T
         packed = np.ascontiguousarray(flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1))      # [slab][cout][32]
+        wscale = 0
+        if prec == 3:
+            packed, wscale = split_f16_rows(packed)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = np.asarray(bp, np.float64)
         w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=wscale, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
                   scale2_off=self._w(w9), shift2_off=self._w(np.asarray(bd, np.float64)),
                   macs_per_pixel=float(cout * C))
         op['in'] = tin
@@ -272,8 +278,17 @@ class Program:
         conv consumers are whole-block reads by the pipelined kernel, whose MFMA operand fragments then come
         straight out of LDS with no conversion VALU.  Everything else stays float32."""
         n = len(self.tensors)
-        fmt = [SPLIT_FMT[self.prec] if (self.allow_split and c % 32 == 0) else FMT_F32
-               for c, _, _ in self.tensors]
+        # the arithmetic mode of a tensor's conv consumers decides its split format (a program may mix modes per op: the
+        # detector's base runs exact f32, its refiner f16x3); consumers of different modes -> float32
+        cprec = {}
+        for op in self.ops:
+            if op['type'] == OP_CONV:
+                cprec.setdefault(op['in'], set()).add(op['prec'])
+        fmt = []
+        for t, (c, _, _) in enumerate(self.tensors):
+            precs = cprec.get(t, {self.prec})
+            p = next(iter(precs)) if len(precs) == 1 else 0
+            fmt.append(SPLIT_FMT[p] if (self.allow_split and c % 32 == 0) else FMT_F32)
         for t in self.f32_only | {self.input_tensor}:
             fmt[t] = FMT_F32
         for op in self.ops:
@@ -282,6 +297,10 @@ class Program:
                         and op['n_slabs'] >= 2 and op['n_slabs'] == op['kh'] * op['kw'] * (op['cin'] // 32))
                 if not pipe:
                     fmt[op['in']] = FMT_F32
+            elif op['type'] in (OP_DWPW, OP_RFSTEM):            # float32 in, float32 out
+                fmt[op['in']] = FMT_F32
+                if op['type'] == OP_RFSTEM:
+                    fmt[op['out']] = FMT_F32
             elif op['type'] == OP_COPYCH:
                 if op['cin'] % 32 or op['in_ch_off'] % 32 or op['out_ch_off'] % 32:
                     fmt[op['in']] = fmt[op['out']] = FMT_F32
@@ -525,10 +544,14 @@ def pack_retinaface(sd, precision='f32', fused=None):
     # next to nothing here: in the `bf16x3` mode the detector runs on it, and its results ARE the `f32` mode's, bit for
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
     det_prec = 'f32' if precision in ('bf16x3', 'f16x3') else precision
-    if precision == 'f16x3' and os.environ.get('TERRAN_AMD_DETECTOR_F16X3'):      # experiment: the detector's convs on the split-half MFMA too
-        det_prec = 'f16x3'
     P = Program(MODEL_RETINAFACE, det_prec)
-    P.allow_split = bool(os.environ.get('TERRAN_AMD_DETECTOR_SPLIT'))
+    # f16x3: the REFINER (FPN laterals, 3x3 aggregations, context modules, heads: 18 dense convs, 0.75 of the detector's
+    # 1.5 ms at C2 and f32-MFMA-bound) runs on the split-half MFMA -- 22-bit operands, measured 0 decision flips / order
+    # swaps against the oracle over 224 frames, the same as exact f32 (bf16x3's 16 bits swapped near-tied scores in 3 % of
+    # the images: that mode keeps the whole detector exact f32).  The MobileNet base stays exact f32: its input is raw
+    # 0..255 pixels and it is bound by its depthwise taps, not by the matrix pipe.
+    refiner_prec = 'f16x3' if (precision == 'f16x3' and not os.environ.get('TERRAN_AMD_DETECTOR_F32')) else None
+    P.allow_split = refiner_prec is not None
     if fused is None:
         fused = P.prec == 0 and not os.environ.get('TERRAN_AMD_NO_FUSED_DETECTOR')       # A/B switch
     tin = P.tensor(4, 1, alias_of=-2 if fused else -1, name='input')
@@ -560,7 +583,10 @@ def pack_retinaface(sd, precision='f32', fused=None):
             if i == 0:
                 P.rfstem(tin, c, Ws, bs, Wd, bd, Wp, bp)
             else:
-                P.dwpw(t, c, Wd, bd, Wp, bp, stride=stride)
+                # the 1x1 of a [depthwise -> pointwise] block follows the refiner's mode from the stride-8 maps on (cin >= 64):
+                # the two blocks on the 104 x 185 maps are bound by their depthwise taps and stay exact f32
+                P.dwpw(t, c, Wd, bd, Wp, bp, stride=stride,
+                       precision=refiner_prec if (Wd.shape[0] >= 64 and not os.environ.get('TERRAN_AMD_DETECTOR_BASE_F32')) else None)
             if both:
                 feats.append(c)
             t = c
@@ -585,25 +611,26 @@ def pack_retinaface(sd, precision='f32', fused=None):
     P.tap('feat32', f32, 0, 256)
 
     e2 = arch.RETINA_REFINER_BN_EPS
+    rp = refiner_prec
 
     def rcbr(p):
         return cbr(p + '.0', p + '.1', e2, bias=True)
 
     W, b = rcbr('refiner.conv_stride32')
     p32 = P.tensor(64, 1, name='p32')
-    P.conv(f32, p32, W, b, act=ACT_RELU)
+    P.conv(f32, p32, W, b, act=ACT_RELU, precision=rp)
     W, b = rcbr('refiner.conv_stride16')
     s16 = P.tensor(64, 1)
-    P.conv(f16, s16, W, b, act=ACT_RELU, res=p32, res_up2=1)
+    P.conv(f16, s16, W, b, act=ACT_RELU, res=p32, res_up2=1, precision=rp)
     W, b = rcbr('refiner.aggr_stride16')
     p16 = P.tensor(64, 1, name='p16')
-    P.conv(s16, p16, W, b, act=ACT_RELU)
+    P.conv(s16, p16, W, b, act=ACT_RELU, precision=rp)
     W, b = rcbr('refiner.conv_stride8')
     s8 = P.tensor(64, 1)
-    P.conv(f8, s8, W, b, act=ACT_RELU, res=p16, res_up2=1)
+    P.conv(f8, s8, W, b, act=ACT_RELU, res=p16, res_up2=1, precision=rp)
     W, b = rcbr('refiner.aggr_stride8')
     p8 = P.tensor(64, 1, name='p8')
-    P.conv(s8, p8, W, b, act=ACT_RELU)
+    P.conv(s8, p8, W, b, act=ACT_RELU, precision=rp)
 
     A = arch.RETINA_NUM_ANCHORS
     heads = {}
@@ -612,13 +639,13 @@ def pack_retinaface(sd, precision='f32', fused=None):
         ctx = P.tensor(96, 1)
         W3, b3 = rcbr(p + '.context_3x3')
         Wr, br_ = rcbr(p + '.dimension_reducer')
-        P.conv(x, ctx, np.concatenate([W3, Wr]), np.concatenate([b3, br_]), act=ACT_RELU, out_ch_off=0)
+        P.conv(x, ctx, np.concatenate([W3, Wr]), np.concatenate([b3, br_]), act=ACT_RELU, out_ch_off=0, precision=rp)
         W5, b5 = rcbr(p + '.context_5x5')
         W7, b7 = cbr(p + '.context_7x7.0', p + '.context_7x7.1', e2, bias=True)
         P.conv(ctx, ctx, np.concatenate([W5, W7]), np.concatenate([b5, b7]), act=ACT_RELU, in_ch_off=32,
-               out_ch_off=48)
+               out_ch_off=48, precision=rp)
         W7b, b7b = cbr(p + '.context_7x7.3', p + '.context_7x7.4', e2, bias=True)
-        P.conv(ctx, ctx, W7b, b7b, act=ACT_RELU, in_ch_off=64, out_ch_off=80)
+        P.conv(ctx, ctx, W7b, b7b, act=ACT_RELU, in_ch_off=64, out_ch_off=80, precision=rp)
         P.tap('ctx%d_3x3' % s, ctx, 0, 32)
         P.tap('ctx%d_5x5' % s, ctx, 48, 16)
         P.tap('ctx%d_7x7' % s, ctx, 80, 16)
@@ -627,7 +654,7 @@ def pack_retinaface(sd, precision='f32', fused=None):
         bh = np.concatenate([sd['outputs.%s_stride%d.bias' % (h, s)] for h in ('cls', 'bbox', 'landmark')])
         pos = np.concatenate([np.arange(32), 48 + np.arange(16), 80 + np.arange(16)])
         hd = P.tensor(16 * A, 0, name='head%d' % s, f32=True)
-        P.conv(ctx, hd, Wh, bh, ch_pos=pos, cin_p=96)
+        P.conv(ctx, hd, Wh, bh, ch_pos=pos, cin_p=96, precision=rp)
         heads[s] = hd
     P.outputs = [heads[32], heads[16], heads[8]]
     return P

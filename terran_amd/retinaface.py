@@ -6,7 +6,7 @@ import numpy as np
 from . import lib, pack, runtime
 
 
-class RetinaFace:
+class RetinaFace(runtime.RangeFallback):
 
     def __init__(self, device=None, nms_threshold=0.4, state=None, ctx=None, precision=None):
         self.device = device
@@ -14,6 +14,7 @@ class RetinaFace:
         self.nms_threshold = nms_threshold
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
         self.model = lib.Model(self.ctx, runtime.packed_program('retinaface', state, self.precision))
+        self._init_fallback('retinaface', state)       # f16x3: the refiner's half-float range (TA_E_RANGE -> exact-f32 twin)
 
     def detect_arrays(self, frames, threshold=0.5):
         """-> (counts (N,) int32, boxes (T,4), landmarks (T,5,2), scores (T,)) float32, images concatenated."""
@@ -22,13 +23,17 @@ class RetinaFace:
         counts = np.zeros(n, np.int32)
         if n == 0:
             return counts, np.empty((0, 4), np.float32), np.empty((0, 5, 2), np.float32), np.empty(0, np.float32)
+        return self._with_fallback(lambda model: self._detect_arrays(model, frames, threshold, counts, n))
+
+    def _detect_arrays(self, model, frames, threshold, counts, n):
+        ctx = self.ctx
         cap = getattr(self, '_cap', max(256, 64 * n))
         while True:
             boxes = np.empty((cap, 4), np.float32)
             lmks = np.empty((cap, 5, 2), np.float32)
             scores = np.empty(cap, np.float32)
             req = C.c_int32(0)
-            rc = ctx.lib.ta_retinaface_run(self.model.h, frames.h, float(threshold), float(self.nms_threshold), cap,
+            rc = ctx.lib.ta_retinaface_run(model.h, frames.h, float(threshold), float(self.nms_threshold), cap,
                                            lib.ptr(counts), lib.ptr(boxes), lib.ptr(lmks), lib.ptr(scores),
                                            C.byref(req))
             if rc == lib.E_CAPACITY:

@@ -173,7 +173,9 @@ def test_retinaface_decisions_vs_oracle(states, case):
     f32, head = table['f32'], table[HEADLINE]
     assert f32['dets'] > 1500
     assert f32['ddets'] <= max(2, f32['dets'] // 1000)
-    assert head == f32                       # the detector runs on the exact-f32 MFMA in every parity mode
+    # f16x3: refiner + deep base on the split-half MFMA (bf16x3 keeps the whole detector exact f32): no worse than f32
+    assert head['ddets'] <= f32['ddets'] + 1 and head['images_reordered'] <= f32['images_reordered'] + 1, table
+    assert table.get('bf16x3', f32) == f32
 
 
 # ---- embeddings (no decisions: the distance to the oracle per mode) -------------------------------------------------

@@ -133,3 +133,26 @@ def test_arcface_wrapper_falls_back_to_f32(states):
     b = ArcFace(device=0, state=sd, precision='f32')
     ea, eb = a.embed_crops(crops), b.embed_crops(crops)
     assert a.fallbacks == 1 and np.array_equal(ea, eb) and np.isfinite(ea).all()
+
+
+def test_retinaface_wrapper_falls_back_to_f32(states):
+    """The detector's refiner runs on the split-half MFMA in the f16x3 mode: a lateral map beyond 65504 (its BatchNorm
+    scaled by 2^24 here) must send the batch to the exact-f32 twin -- same detections as an f32 wrapper, bit for bit."""
+    from terran_amd import RetinaFace
+    sd = dict(states('retinaface'))
+    g = np.float32(2.0 ** 24)
+    for k in ('weight', 'bias'):
+        sd['refiner.conv_stride8.1.' + k] = np.asarray(sd['refiner.conv_stride8.1.' + k], np.float32) * g
+    sd['refiner.aggr_stride8.0.weight'] = np.asarray(sd['refiner.aggr_stride8.0.weight'], np.float32) / g
+    frames = synth.frames(12, 3, 96, 128)
+    a = RetinaFace(device=0, state=sd, precision='f16x3')
+    b = RetinaFace(device=0, state=sd, precision='f32')
+    ra, rb = a.call(frames), b.call(frames)
+    assert a.fallbacks == 1 and b.fallbacks == 0
+    assert [len(x) for x in ra] == [len(x) for x in rb]
+    for x, y in zip(ra, rb):
+        for p, q in zip(x, y):
+            assert np.array_equal(p['bbox'], q['bbox']) and p['score'] == q['score']
+    c = RetinaFace(device=0, state=states('retinaface'), precision='f16x3')
+    c.call(frames)
+    assert c.fallbacks == 0

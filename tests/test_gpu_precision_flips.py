@@ -23,8 +23,9 @@ def _det_keys(dets):
 
 @pytest.mark.parametrize('mode', ['f16x3', 'bf16x3'])
 def test_retinaface_decisions_f32_vs_split_modes(states, mode):
-    """The detector runs on the exact-f32 MFMA in EVERY parity mode (pack.pack_retinaface: with bf16x3 convs 6 of 208
-    images came back with near-tied scores in a different order): same detections, same order, same bits."""
+    """bf16x3: the detector runs on the exact-f32 MFMA (with bf16x3 convs 6 of 208 images came back with near-tied scores
+    in a different order): same detections, same order, same bits as `f32`.  f16x3: its refiner and the deep half of its
+    base run on the split-half MFMA (22-bit operands): the same detections; a near-tie may swap."""
     from terran_amd import RetinaFace
     a = RetinaFace(device=0, state=states('retinaface'), precision='f32')
     b = RetinaFace(device=0, state=states('retinaface'), precision=mode)
@@ -46,7 +47,10 @@ def test_retinaface_decisions_f32_vs_split_modes(states, mode):
     print('retinaface f32 vs split modes: %d images, %d detections; %d images differ (%d detections); max |bbox/score| diff '
           'on identical sets %.2e' % (n_img, n_det, diff_img, diff_det, worst))
     assert n_det > 5000
-    assert diff_img == 0 and diff_det == 0 and worst == 0.0
+    if mode == 'bf16x3':
+        assert diff_img == 0 and diff_det == 0 and worst == 0.0
+    else:                                              # measured: 0 images, 0 detections, 1.2e-4 px / 2e-7 score
+        assert diff_img <= 2 and diff_det <= 2 and worst < 2e-3
 
 
 # measured (MI355X, 208 frames): f16x3 differs from f32 in <= 2 of 16 468 peaks, 0 connections, 0 humans;
