@@ -80,15 +80,19 @@ class RangeFallback:
     exact-f32 MFMA (same weights, float32 range), built on first use; `fallbacks` counts how often that happened."""
 
     def _init_fallback(self, kind, state):
-        self._fb_kind, self._fb_state, self._fb_model, self.fallbacks = kind, state, None, 0
+        self._fb_kind, self._fb_state, self._fb_model, self.fallbacks, self._fb_calls = kind, state, None, 0, 0
 
     def _with_fallback(self, fn):
-        """fn(model) -> result; re-run on the f32 model when the f16x3 one reports TA_E_RANGE."""
-        try:
-            return fn(self.model)
-        except lib.TerranAmdError as e:
-            if e.code != lib.E_RANGE:
-                raise
+        """fn(model) -> result; re-run on the f32 model when the f16x3 one reports TA_E_RANGE.  Weights whose activations
+        leave the half-float range on (nearly) every batch would pay for two runs per call: once the first three calls have
+        all fallen back, the exact-f32 model simply takes over."""
+        self._fb_calls += 1
+        if not (self.fallbacks >= 3 and self.fallbacks == self._fb_calls - 1):
+            try:
+                return fn(self.model)
+            except lib.TerranAmdError as e:
+                if e.code != lib.E_RANGE:
+                    raise
         if self._fb_model is None:
             self._fb_model = lib.Model(self.ctx, packed_program(self._fb_kind, self._fb_state, 'f32'))
         self.fallbacks += 1
