@@ -156,6 +156,7 @@ def main():
     ap.add_argument('--devices', default=None, help='with --single-process: comma-separated device ids (repeats allowed)')
     args = ap.parse_args()
 
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')     # before torch initialises HIP: see terran_amd/lib.py:load
     # stdout carries exactly ONE line (the JSON): everything libraries print to fd 1 (RCCL's version banner, for
     # one) is sent to stderr instead, and the result is written to the saved descriptor at the end.
     sys.stdout.flush()
@@ -607,6 +608,7 @@ def run(args):
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
                 'streams_per_gpu': 4 * L,
+                'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                 'batches_in_flight_per_gpu': L,
                 'step_overlap': 'serial: one kernel at a time' if args.serial else
                                 'one step at a time' if args.join_steps else
