@@ -108,6 +108,14 @@ __device__ __forceinline__ int ta_xcd_tile(int n_pt, int xcd, int local) {
   return xcd * base + (xcd < rem ? xcd : rem) + local;
 }
 
+// A conv that FOLDS a per-channel affine of its INPUT (ArcFace's BatchNorm in front of a zero-padded 3x3 conv,
+// arcface/model.py:12-14) into its weights needs a bias that depends on which filter taps fall into the padding: the
+// shift reaches the sum only through in-bounds taps.  Nine classes (top / middle / bottom) x (left / middle / right);
+// bias9[class][coutp], class 4 (interior) == the ordinary bias.  3x3, stride 1, pad 1 only.
+__device__ __forceinline__ int ta_border_class(int y, int x, int Ho, int Wo) {
+  return (y == 0 ? 0 : (y == Ho - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == Wo - 1 ? 2 : 1));
+}
+
 // Fused epilogue shared by both kernels.  acc[a][b][r]: pixel = tile col (lane&31);
 // cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the 32x32 tile.
 template <int WM_TILES, int WN_TILES>
@@ -150,6 +158,19 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, bias[a][j][e]);   // us == 1: acc + bias
+    if (p.bias9) {                                      // border pixels: the class's bias instead (see ta_border_class)
+      const int cls = ta_border_class(y, x, p.Ho, p.Wo);
+      if (cls != 4) {
+#pragma unroll
+        for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 b9 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co_base + a * 32 + 8 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, b9[e]);
+          }
+      }
+    }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
       for (int a = 0; a < WM_TILES; ++a)
@@ -1091,10 +1112,18 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     ta_f32x8 v;
     v.a = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
     v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+    f32x4 bb0 = bias0, bb1 = bias1;
+    if (p.bias9) {
+      const int cls = ta_border_class(y, x, p.Ho, p.Wo);
+      if (cls != 4) {
+        bb0 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
+        bb1 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co + 4);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v.a[e] = __builtin_fmaf(v.a[e], us, bias0[e]);
-      v.b[e] = __builtin_fmaf(v.b[e], us, bias1[e]);
+      v.a[e] = __builtin_fmaf(v.a[e], us, bb0[e]);
+      v.b[e] = __builtin_fmaf(v.b[e], us, bb1[e]);
     }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
@@ -1171,7 +1200,8 @@ __device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], fl
     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));   // one v_max3_f32 per pair
   }
 }
-template <int BN, int BM, int NT, int ACT, bool RES, bool F16, bool POOL = false>     // RES: + shortcut, and the second (affine) output; POOL: fused 2x2 max-pool
+template <int BN, int BM, int NT, int ACT, bool RES, bool F16, bool POOL = false, bool OUT2 = RES, bool B9 = false>
+// RES: + shortcut; OUT2: the second (affine) output; POOL: fused 2x2 max-pool; B9: border-class bias (ta_border_class)
 __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
   constexpr int NCH = BN / 4;
   constexpr int G = BN / 8;
@@ -1186,7 +1216,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     *(f32x4*)sl = *(const f32x4*)(p.prelu + co);
     *(f32x4*)(sl + 4) = *(const f32x4*)(p.prelu + co + 4);
   }
-  if (RES) {
+  if (OUT2) {
     *(f32x4*)sc = *(const f32x4*)(p.scale2 + co);
     *(f32x4*)(sc + 4) = *(const f32x4*)(p.scale2 + co + 4);
     *(f32x4*)sh = *(const f32x4*)(p.shift2 + co);
@@ -1197,7 +1227,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
   float amax = 0.f;
   char* const ob = (char*)p.out + chan(p.out_ch + co);
   const char* const rb = RES ? (const char*)p.res + chan(p.res_ch + co) : nullptr;
-  char* const o2b = RES ? (char*)p.out2 + chan(p.o2_ch + co) : nullptr;
+  char* const o2b = OUT2 ? (char*)p.out2 + chan(p.o2_ch + co) : nullptr;
   // POOL: rows 4 w .. 4 w + 3 of the staged tile are the pixels of window w (lanes G and 2 G apart hold the same 8
   // channels of a window's other rows); coordinates below are those of the POOLED map and a pass advances STEP of its pixels
   static_assert(!POOL || (4 * G <= 64 && (RPI & 3) == 0), "a window's four rows live in one wave");
@@ -1222,10 +1252,20 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
       *(uint4*)rh = *(const uint4*)rs;
       *(uint4*)rl = *(const uint4*)(rs + 64);
     }
+    float bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = bias[e];
+    if (B9) {
+      const int cls = ta_border_class(y, x, p.Ho, p.Wo);
+      if (cls != 4) {
+        *(f32x4*)bb = *(const f32x4*)(p.bias9 + cls * p.coutp + co);
+        *(f32x4*)(bb + 4) = *(const f32x4*)(p.bias9 + cls * p.coutp + co + 4);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (F16) v[e] = __builtin_fmaf(v[e], us, bias[e]);      // weights were packed times 2^wscale_log2
-      else v[e] += bias[e];
+      if (F16) v[e] = __builtin_fmaf(v[e], us, bb[e]);      // weights were packed times 2^wscale_log2
+      else v[e] += bb[e];
       if (ACT == TA_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
       if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
     }
@@ -1247,7 +1287,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     }
     if (!POOL || (row & 3) == 0)
       ta_split_store8<F16>(ob + 4u * (unsigned)(img * p.out_img + y * p.out_row + x * p.out_pix + p.out_off0), v, amax);
-    if (RES) {
+    if (OUT2) {
       float z[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = v[e] * sc[e] + sh[e];
@@ -1289,14 +1329,22 @@ __device__ __forceinline__ bool conv_drain_dispatch(const ta_conv_launch& p, con
     }
     return false;
   }
+  if (p.bias9) {                                      // ArcFace unit-opening convs: folded input BatchNorm, PReLU
+    if (p.act == TA_ACT_PRELU && !p.res && !p.out2) {
+      conv_drain_fast<BN, BM, NT, TA_ACT_PRELU, false, F16, false, false, true>(p, lds, ct0, pt0, tid, HoWo);
+      return true;
+    }
+    return false;
+  }
   if (!p.res && !p.out2) {
     if (p.act == TA_ACT_RELU) conv_drain_fast<BN, BM, NT, TA_ACT_RELU, false, F16>(p, lds, ct0, pt0, tid, HoWo);
     else if (p.act == TA_ACT_PRELU) conv_drain_fast<BN, BM, NT, TA_ACT_PRELU, false, F16>(p, lds, ct0, pt0, tid, HoWo);
     else conv_drain_fast<BN, BM, NT, TA_ACT_NONE, false, F16>(p, lds, ct0, pt0, tid, HoWo);
     return true;
   }
-  if (p.res && p.out2 && p.act == TA_ACT_NONE) {
-    conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true, F16>(p, lds, ct0, pt0, tid, HoWo);
+  if (p.res && p.act == TA_ACT_NONE) {                // unit-closing convs: + shortcut, with or without the second output
+    if (p.out2) conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true, F16, false, true>(p, lds, ct0, pt0, tid, HoWo);
+    else conv_drain_fast<BN, BM, NT, TA_ACT_NONE, true, F16, false, false>(p, lds, ct0, pt0, tid, HoWo);
     return true;
   }
   return false;
@@ -1568,7 +1616,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
   const int HoWo = p.Ho * p.Wo;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int pix = i / c4, co = (i - pix * c4) * 4;
+    const int img = pix / HoWo;
+    const int rem = pix - img * HoWo;
+    const int y = rem / p.Wo, x = rem - y * p.Wo;
     f32x4 v = *(const f32x4*)(p.bias + co);
+    if (p.bias9) {
+      const int cls = ta_border_class(y, x, p.Ho, p.Wo);
+      if (cls != 4) v = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
+    }
     for (int k = 0; k < p.k_split; ++k) {
       const f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * p.M + pix) * p.coutp + co);
 #pragma unroll
@@ -1582,9 +1637,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
     }
-    const int img = pix / HoWo;
-    const int rem = pix - img * HoWo;
-    const int y = rem / p.Wo, x = rem - y * p.Wo;
     if (p.res) {                                     // the same order as the one-pass epilogues: activation, + shortcut, store, second output
       const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
       const f32x4 r = ta_ld4(p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0, p.res_ch + co, p.res_fmt);

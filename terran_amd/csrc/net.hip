@@ -375,6 +375,7 @@ int ta_model_run_ops(ta_model* m) {
           p.group_cin = op.cin;
         }
         p.variant = op.variant & 255;
+        if ((op.variant >> 16) & 1) p.bias9 = wptr(m, op.scale2_off);
         p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
@@ -499,7 +500,9 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
             op.stride <= 0 || op.wscale_log2 < -60 || op.wscale_log2 > 60 || (op.prec != 3 && op.wscale_log2 != 0) || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
-            (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0));
+            (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||
+            (((op.variant >> 16) & 1) && (op.out2 >= 0 || op.scale2_off < 0 || op.kh != 3 || op.kw != 3 || op.stride != 1 || op.pad != 1 ||
+                                          op.pool || bad_w(op.scale2_off, (size_t)9 * op.coutp * 4)));
     } else if (op.type == TA_OP_RFSTEM) {
       bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
     } else if (op.type == TA_OP_DWPW) {

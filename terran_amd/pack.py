@@ -128,7 +128,7 @@ class Program:
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-             scale2=None, shift2=None, groups=1, variant=0, pool=False, k_split=0, precision=None):
+             scale2=None, shift2=None, groups=1, variant=0, pool=False, k_split=0, precision=None, in_affine=None):
         """W: (cout, cin, kh, kw) float (BN already folded), bias: (cout,).
         ch_pos[ci] = position of true input channel ci inside the slice [in_ch_off, in_ch_off+cin_p).
         groups > 1: W is (cout, cin / groups, kh, kw) as in torch; group g reads input channels
@@ -136,12 +136,26 @@ class Program:
         of 32 and cout_g of 128 (a 128-channel output tile never straddles two groups).
         variant != 0 pins the conv to one kernel variant (lib.CONV_VARIANTS; parity tests): loading fails when that
         kernel cannot run the layer.
+        in_affine=(scale, shift) per input channel: the conv computes conv(pad0(scale * x + shift)) -- ArcFace's BatchNorm in
+        front of a zero-padded conv (arcface/model.py:12-14) -- with the scale folded into the weights and the shift into NINE
+        biases, one per border class of the output pixel (the shift reaches the sum only through taps that are not padding;
+        3x3, stride 1, pad 1 only).  The input tensor is then read raw: no BatchNorm'd copy of it has to exist.
         k_split > 1: the layer's K is cut in that many fixed ranges (one workgroup each, ordered reduction): for layers whose
         output is too small to fill the chip at any batch in use.  A property of the LAYER, never of the batch.
         pool=True fuses the 2x2 / 2 max-pool that follows the conv (+ activation) into its epilogue: `tout` is the POOLED
         tensor (split-role kernel only: cin % 32 == 0, cout % 64 == 0, plain epilogue)."""
         W = np.asarray(W, dtype=np.float64)
         cout, cin, kh, kw = W.shape
+        bias9 = None
+        if in_affine is not None:
+            assert (kh, kw, stride) == (3, 3, 1) and pad in (None, 1) and groups == 1 and out2 < 0 and scale2 is None and not pool
+            a_s, a_t = (np.asarray(v, np.float64) for v in in_affine)
+            T = np.einsum('ocyx,c->oyx', W, a_t)                          # what the shift adds through tap (ky, kx)
+            W = W * a_s[None, :, None, None]
+            b0 = np.zeros(cout) if bias is None else np.asarray(bias, np.float64)
+            valid = ([1, 2], [0, 1, 2], [0, 1])                           # in-bounds taps of a first / middle / last row or column
+            bias9 = np.stack([b0 + T[:, valid[cy]][:, :, valid[cx]].sum((1, 2)) for cy in range(3) for cx in range(3)])
+            bias = bias9[4]
         if groups > 1:
             assert cout % groups == 0 and cin % 32 == 0 and (cout // groups) % 128 == 0 and ch_pos is None
         if pad is None:
@@ -175,10 +189,16 @@ class Program:
             out = np.zeros(coutp, np.float32)
             out[:cout] = np.asarray(v, dtype=np.float64)
             return self._w(out)
+        if bias9 is not None:                                             # [9][coutp] in the place of the (absent) second output's scale
+            t9 = np.zeros((9, coutp), np.float32)
+            t9[:, :cout] = bias9
+            scale2_off9 = self._w(t9)
+            variant |= 1 << 16
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
-                  groups=groups, variant=variant | (int(k_split) << 8), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu), scale2_off=vec(scale2),
+                  groups=groups, variant=variant | (int(k_split) << 8), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu),
+                  scale2_off=scale2_off9 if bias9 is not None else vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         self.ops.append(op)
@@ -468,14 +488,18 @@ def pack_openpose(sd, precision='f32'):
 
 # ---- ArcFace -------------------------------------------------------------------------------
 def pack_arcface(sd, precision='f32'):
-    """arcface/model.py:4-97.  The residual stream R is kept raw (halo 0); each conv that
-    closes a unit also emits Z = BN_next(R) (halo 1) for the next unit's first conv, so the
-    pre-conv BatchNorm (model.py:12) is applied before zero padding exactly as the reference does."""
+    """arcface/model.py:4-97.  The residual stream R is the only tensor between units (halo 1).  A unit opens with a
+    BatchNorm in front of a zero-padded 3x3 conv (model.py:12-14): folding it into that conv is exact away from the border
+    only -- padded taps are true zeros, not BN(0) -- so the conv gets NINE biases, one per border class of the output pixel
+    (Program.conv(in_affine=...)): the BatchNorm'd copy of R the unit-closing conv used to write as a second output
+    (TERRAN_AMD_ARCFACE_SECOND_OUTPUT=1 keeps that program) is gone, and with it one of the two store streams of every
+    unit-closing epilogue."""
     eps = arch.ARC_BN_EPS
     P = Program(MODEL_ARCFACE, precision)
     tin = P.tensor(4, 1, name='input')
     P.input_tensor = tin
     units = list(arch.arcface_units())
+    second = bool(os.environ.get('TERRAN_AMD_ARCFACE_SECOND_OUTPUT'))
 
     def next_bn(i):
         if i < len(units):
@@ -485,10 +509,14 @@ def pack_arcface(sd, precision='f32'):
 
     s, sh = _bn_affine(sd, 'initial_layer.1', eps)
     W, b = _fold(sd['initial_layer.0.weight'], None, s, sh)
-    R = P.tensor(64, 0, name='stem')
-    s2, sh2 = next_bn(0)
-    Z = P.tensor(64, 1)
-    P.conv(tin, R, W, b, act=ACT_PRELU, prelu=sd['initial_layer.2.weight'], out2=Z, scale2=s2, shift2=sh2)
+    R = P.tensor(64, 0 if second else 1, name='stem')
+    Z = None
+    if second:
+        s2, sh2 = next_bn(0)
+        Z = P.tensor(64, 1)
+        P.conv(tin, R, W, b, act=ACT_PRELU, prelu=sd['initial_layer.2.weight'], out2=Z, scale2=s2, shift2=sh2)
+    else:
+        P.conv(tin, R, W, b, act=ACT_PRELU, prelu=sd['initial_layer.2.weight'])
     for i, (st, u, cin, cout, stride, sc) in enumerate(units):
         p = 'stages.%d.%d' % (st, u)
         s, sh = _bn_affine(sd, p + '.body.2', eps)
@@ -496,7 +524,11 @@ def pack_arcface(sd, precision='f32'):
         Y = P.tensor(cout, 1)
         # stage 4 (7 x 7 maps, 512 channels): 100 output tiles at 64 crops on 256 CUs, 144 K slabs -> K in two fixed halves
         ks = 2 if (cout == 512 and not os.environ.get('TERRAN_AMD_NO_STAGE4_KSPLIT')) else 0
-        P.conv(Z, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'], k_split=ks if cin == 512 else 0)
+        if second:
+            P.conv(Z, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'], k_split=ks if cin == 512 else 0)
+        else:
+            P.conv(R, Y, W1, b1, act=ACT_PRELU, prelu=sd[p + '.body.3.weight'], k_split=ks if cin == 512 else 0,
+                   in_affine=next_bn(i))
         if sc:
             s, sh = _bn_affine(sd, p + '.shortcut.1', eps)
             Ws, bs = _fold(sd[p + '.shortcut.0.weight'], None, s, sh)
@@ -508,20 +540,32 @@ def pack_arcface(sd, precision='f32'):
         s, sh = _bn_affine(sd, p + '.body.5', eps)
         W2, b2 = _fold(sd[p + '.body.4.weight'], None, s, sh)
         last = i == len(units) - 1
-        Rn = P.tensor(cout, 0)
-        Zn = P.tensor(cout, 0 if last else 1)
-        s2, sh2 = next_bn(i + 1)
-        P.conv(Y, Rn, W2, b2, stride=stride, res=res, out2=Zn, scale2=s2, shift2=sh2, k_split=ks)
+        Rn = P.tensor(cout, 0 if (second or last) else 1)
+        if second:
+            Zn = P.tensor(cout, 0 if last else 1)
+            s2, sh2 = next_bn(i + 1)
+            P.conv(Y, Rn, W2, b2, stride=stride, res=res, out2=Zn, scale2=s2, shift2=sh2, k_split=ks)
+            Z = Zn
+        else:
+            P.conv(Y, Rn, W2, b2, stride=stride, res=res, k_split=ks)
         if u == arch.ARC_UNITS[st] - 1:
             P.tap('stage%d' % (st + 1), Rn, 0, cout)
-        R, Z = Rn, Zn
-    # head: Flatten(C,H,W) -> Linear -> BN1d, as a 1x1 conv over the (N,1,1,25088) NHWC view of Z
-    A = P.tensor(7 * 7 * 512, 0, alias_of=Z)
+        R = Rn
+    # head: BN2d -> Flatten(C,H,W) -> Linear -> BN1d, as a 1x1 conv over the (N,1,1,25088) NHWC view
     s, sh = _bn_affine(sd, 'final_layer.4', eps)
     Wl = np.asarray(sd['final_layer.3.weight'], np.float64) * s[:, None]
     bl = np.asarray(sd['final_layer.3.bias'], np.float64) * s + sh
     f = np.arange(7 * 7 * 512)
     ch_pos = (f % 49) * 512 + f // 49
+    if second:
+        A = P.tensor(7 * 7 * 512, 0, alias_of=Z)
+    else:
+        # no padding between final_layer.0 and the Linear: that BatchNorm folds into the Linear exactly
+        s0, t0 = next_bn(len(units))
+        chan = f // 49                                          # flatten order (C, H, W): feature f belongs to channel f // 49
+        bl = bl + Wl @ t0[chan]
+        Wl = Wl * s0[chan][None, :]
+        A = P.tensor(7 * 7 * 512, 0, alias_of=R)
     E = P.tensor(512, 0, name='embedding', f32=True)
     P.conv(A, E, Wl.reshape(512, 7 * 7 * 512, 1, 1), bl, ch_pos=ch_pos, pad=0)
     P.outputs = [E]

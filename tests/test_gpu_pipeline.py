@@ -266,6 +266,25 @@ def test_openpose_lists_grow_beyond_the_fast_path(ctx):
     assert len(again[0]) == len(ref[0])
 
 
+def test_openpose_several_images_outgrow_the_fast_path(ctx):
+    """Two of four images carry a plateau (different parts), the plateau image is also the LAST one: each is re-run on its
+    own, results are spliced back in image order, and the debug taps of every image stay readable."""
+    from oracle import openpose_post
+    from terran_amd import openpose
+    hm, paf = synth.pose_maps_batch(8, 4, 2, 16, 24)
+    hm[0, 3, 3:11, 4:13] = 0.6
+    hm[3, 7, 2:10, 8:18] = 0.45
+    ref = openpose_post.postprocess(paf, hm, 1.3)
+    got = openpose.group(ctx, paf, hm, 1.3)
+    assert [len(g) for g in got] == [len(r) for r in ref]
+    for gp, rp in zip(got, ref):
+        for a, b in zip(gp, rp):
+            assert np.array_equal(a['keypoints'], b['keypoints']) and a['score'] == b['score']
+    peaks, _ = ctx.pose_debug(4, cap_peaks=4096, cap_conn=1024)
+    assert len(peaks[0][3][1]) > 1024 and len(peaks[3][7][1]) > 1024
+    _assert_stage_taps_equal(ctx, 4, hm, paf, scale=1.3, caps=4096)
+
+
 def test_openpose_large_maps_take_the_global_memory_kernels(ctx):
     """Maps too large for the grouping kernels' LDS staging (1080p at native resolution: 135 x 240 cells) run on the
     same kernels reading a planar copy of the maps from global memory: == oracle."""

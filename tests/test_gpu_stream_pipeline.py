@@ -74,3 +74,18 @@ def test_stream_pipeline_propagates_errors(states):
             list(pipe.run([np.zeros((2, 64, 64, 4), np.uint8)]))        # 4 channels: the upload asserts
     finally:
         pipe.close()
+
+
+def test_stream_pipeline_without_faces(states):
+    """Frames on which nothing is detected (threshold above every score) still yield their (empty) embeddings and poses."""
+    from terran_amd.pipeline import StreamPipeline
+    kw = dict(detection_kw=dict(short_side=64, state=states('retinaface')), recognition_kw=dict(state=states('arcface')),
+              estimation_kw=dict(short_side=64, state=states('openpose')))
+    pipe = StreamPipeline([0], inflight=2, pick_faces=lambda dets: [[] for _ in dets], **kw)
+    try:
+        out = list(pipe.run([synth.frames(5, 3, 64, 96), synth.frames(6, 2, 64, 96)]))
+    finally:
+        pipe.close()
+    assert [len(t[0]) for t in out] == [3, 2]
+    for dets, feats, poses in out:
+        assert all(f.shape == (0, 512) for f in feats) and len(poses) == len(dets)
