@@ -110,10 +110,14 @@ __device__ __forceinline__ int ta_xcd_tile(int n_pt, int xcd, int local) {
 
 // A conv that FOLDS a per-channel affine of its INPUT (ArcFace's BatchNorm in front of a zero-padded 3x3 conv,
 // arcface/model.py:12-14) into its weights needs a bias that depends on which filter taps fall into the padding: the
-// shift reaches the sum only through in-bounds taps.  Nine classes (top / middle / bottom) x (left / middle / right);
-// bias9[class][coutp], class 4 (interior) == the ordinary bias.  3x3, stride 1, pad 1 only.
+// shift reaches the sum only through in-bounds taps.  Per axis a pixel is first / middle / last -- or the only one (maps of
+// one row or column: both outer taps are padding): 4 x 4 classes, bias9[class][coutp] (nine of them occur on maps of two or
+// more rows and columns), TA_INTERIOR (middle, middle) == the ordinary bias.  3x3, stride 1, pad 1 only.
+#define TA_INTERIOR 5
 __device__ __forceinline__ int ta_border_class(int y, int x, int Ho, int Wo) {
-  return (y == 0 ? 0 : (y == Ho - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == Wo - 1 ? 2 : 1));
+  const int cy = Ho == 1 ? 3 : (y == 0 ? 0 : (y == Ho - 1 ? 2 : 1));
+  const int cx = Wo == 1 ? 3 : (x == 0 ? 0 : (x == Wo - 1 ? 2 : 1));
+  return cy * 4 + cx;
 }
 
 // Fused epilogue shared by both kernels.  acc[a][b][r]: pixel = tile col (lane&31);
@@ -160,7 +164,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
         for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, bias[a][j][e]);   // us == 1: acc + bias
     if (p.bias9) {                                      // border pixels: the class's bias instead (see ta_border_class)
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
-      if (cls != 4) {
+      if (cls != TA_INTERIOR) {
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
@@ -1115,7 +1119,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     f32x4 bb0 = bias0, bb1 = bias1;
     if (p.bias9) {
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
-      if (cls != 4) {
+      if (cls != TA_INTERIOR) {
         bb0 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
         bb1 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co + 4);
       }
@@ -1257,7 +1261,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     for (int e = 0; e < 8; ++e) bb[e] = bias[e];
     if (B9) {
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
-      if (cls != 4) {
+      if (cls != TA_INTERIOR) {
         *(f32x4*)bb = *(const f32x4*)(p.bias9 + cls * p.coutp + co);
         *(f32x4*)(bb + 4) = *(const f32x4*)(p.bias9 + cls * p.coutp + co + 4);
       }
@@ -1622,7 +1626,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     f32x4 v = *(const f32x4*)(p.bias + co);
     if (p.bias9) {
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
-      if (cls != 4) v = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
+      if (cls != TA_INTERIOR) v = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
     }
     for (int k = 0; k < p.k_split; ++k) {
       const f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * p.M + pix) * p.coutp + co);

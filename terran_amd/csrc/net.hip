@@ -502,7 +502,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||
             (((op.variant >> 16) & 1) && (op.out2 >= 0 || op.scale2_off < 0 || op.kh != 3 || op.kw != 3 || op.stride != 1 || op.pad != 1 ||
-                                          op.pool || bad_w(op.scale2_off, (size_t)9 * op.coutp * 4)));
+                                          op.pool || bad_w(op.scale2_off, (size_t)16 * op.coutp * 4)));
     } else if (op.type == TA_OP_RFSTEM) {
       bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
     } else if (op.type == TA_OP_DWPW) {

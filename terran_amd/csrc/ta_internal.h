@@ -63,7 +63,7 @@ struct ta_op_desc {
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
   int32_t variant;                    // bits 0..7: 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests);
                                       // bits 8..15: K-split factor fixed by the packer for this layer (0 = the library's rule);
-                                      // bit 16: `scale2_off` holds a border-class bias table [9][coutp] (3x3, stride 1, pad 1, no
+                                      // bit 16: `scale2_off` holds a border-class bias table [16][coutp] (3x3, stride 1, pad 1, no
                                       // second output): a per-channel affine of the INPUT is folded into the weights
   int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
   int32_t wscale_log2;                // f16x3: the packed weights are W * 2^wscale_log2 (their lo halves stay normal half floats);
@@ -265,7 +265,7 @@ struct ta_conv_launch {
   int fast_drain;                              // 1: the lean epilogue applies (split-format tensors below 4 GB, cout % 8 == 0, no pool / K-split)
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
-  const float* bias9;                          // border-class biases [9][coutp] of a conv with a folded input affine (nullptr: none)
+  const float* bias9;                          // border-class biases [16][coutp] of a conv with a folded input affine (nullptr: none)
   float w_unscale;                             // sums are multiplied by this before the bias (2^-wscale_log2; 1 outside f16x3)
   int* range_flag;                             // set to 1 by an epilogue that writes |x| > 65504 into a TA_FMT_SPLIT16 tensor
 };

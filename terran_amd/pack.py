@@ -137,8 +137,8 @@ class Program:
         variant != 0 pins the conv to one kernel variant (lib.CONV_VARIANTS; parity tests): loading fails when that
         kernel cannot run the layer.
         in_affine=(scale, shift) per input channel: the conv computes conv(pad0(scale * x + shift)) -- ArcFace's BatchNorm in
-        front of a zero-padded conv (arcface/model.py:12-14) -- with the scale folded into the weights and the shift into NINE
-        biases, one per border class of the output pixel (the shift reaches the sum only through taps that are not padding;
+        front of a zero-padded conv (arcface/model.py:12-14) -- with the scale folded into the weights and the shift into
+        one bias per border class of the output pixel (nine on ordinary maps) (the shift reaches the sum only through taps that are not padding;
         3x3, stride 1, pad 1 only).  The input tensor is then read raw: no BatchNorm'd copy of it has to exist.
         k_split > 1: the layer's K is cut in that many fixed ranges (one workgroup each, ordered reduction): for layers whose
         output is too small to fill the chip at any batch in use.  A property of the LAYER, never of the batch.
@@ -153,9 +153,9 @@ class Program:
             T = np.einsum('ocyx,c->oyx', W, a_t)                          # what the shift adds through tap (ky, kx)
             W = W * a_s[None, :, None, None]
             b0 = np.zeros(cout) if bias is None else np.asarray(bias, np.float64)
-            valid = ([1, 2], [0, 1, 2], [0, 1])                           # in-bounds taps of a first / middle / last row or column
-            bias9 = np.stack([b0 + T[:, valid[cy]][:, :, valid[cx]].sum((1, 2)) for cy in range(3) for cx in range(3)])
-            bias = bias9[4]
+            valid = ([1, 2], [0, 1, 2], [0, 1], [1])                      # in-bounds taps of a first / middle / last / ONLY row or column
+            bias9 = np.stack([b0 + T[:, valid[cy]][:, :, valid[cx]].sum((1, 2)) for cy in range(4) for cx in range(4)])
+            bias = bias9[5]                                               # (middle, middle): the interior
         if groups > 1:
             assert cout % groups == 0 and cin % 32 == 0 and (cout // groups) % 128 == 0 and ch_pos is None
         if pad is None:
@@ -190,7 +190,7 @@ class Program:
             out[:cout] = np.asarray(v, dtype=np.float64)
             return self._w(out)
         if bias9 is not None:                                             # [9][coutp] in the place of the (absent) second output's scale
-            t9 = np.zeros((9, coutp), np.float32)
+            t9 = np.zeros((16, coutp), np.float32)
             t9[:, :cout] = bias9
             scale2_off9 = self._w(t9)
             variant |= 1 << 16

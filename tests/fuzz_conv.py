@@ -46,6 +46,9 @@ def draw(rng):
         case['out_total'] = tot
         case['out_off'] = int(rng.choice([0, 32, tot - (cout + 3) // 4 * 4])) // 4 * 4
     case['act'] = int(rng.choice([0, 1, 2]))
+    if k == 3 and case.get('stride', 1) == 1 and 'cin_used' not in case and rng.random() < 0.25:
+        case['in_affine'] = True                 # folded input affine + border-class biases (no second output with it)
+        return case
     if rng.random() < 0.3 and 'out_total' not in case:
         case['res'] = True
     if rng.random() < 0.2 and 'out_total' not in case:

@@ -47,6 +47,11 @@ def op_case(ctx, rng):
     scale = float(rng.choice([1.0, 0.37, 1.7, 0.17]))
     kw = dict(noise=float(rng.choice([0.0, 0.01, 0.05])), drop_prob=float(rng.choice([0.0, 0.1, 0.4])))
     hm, paf = synth.pose_maps_batch(seed, n, P, h, w, **kw)
+    if rng.random() < 0.08 and h >= 10 and w >= 12:      # a plateau: > 1024 peaks of one part -> the global-memory re-run
+        i, part = int(rng.integers(0, n)), int(rng.integers(0, 18))
+        y0, x0 = int(rng.integers(1, h - 8)), int(rng.integers(1, w - 10))
+        hm[i, part, y0:y0 + 7, x0:x0 + 9] = float(rng.choice([0.3, 0.5, 0.9]))
+        kw = dict(kw, plateau=(i, part))
     ref = openpose_post.postprocess(paf, hm, scale)
     try:
         got = openpose.group(ctx, paf, hm, scale)

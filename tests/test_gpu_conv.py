@@ -38,6 +38,14 @@ CASES = [
     dict(c1=256, cout=256, k=3, groups=2),
     dict(c1=256, cout=256, k=7, halo=3, groups=2, n=3, h=23, w=40),
     dict(c1=384, cout=256, k=1, groups=2, in_off=128, cin_used=256, act=1),
+    # a per-channel affine of the INPUT in front of the zero-padded 3x3 conv, folded into weights + nine border-class biases
+    # (ArcFace's BatchNorm-before-conv, arcface/model.py:12-14): split-role kernel (lean and generic drains), generic kernel,
+    # maps of one row / one column (every pixel is a border pixel of two classes at once)
+    dict(c1=128, cout=128, k=3, act=2, in_affine=True, n=3, h=14, w=14),
+    dict(c1=64, cout=64, k=3, act=2, in_affine=True, n=2, h=7, w=9),
+    dict(c1=256, cout=256, k=3, act=0, in_affine=True, n=2, h=1, w=5),
+    dict(c1=32, cout=16, k=3, act=1, in_affine=True, h=6, w=1),
+    dict(c1=16, cout=32, k=3, act=2, in_affine=True, h=5, w=5),
 ]
 
 
@@ -91,6 +99,10 @@ def test_conv(ctx, case, precision):
         scale2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
         shift2 = rng.normal(0, 0.2, cout).astype(np.float32)
         kw.update(out2=t3, scale2=scale2, shift2=shift2)
+    aff = None
+    if case.get('in_affine'):
+        aff = (rng.uniform(0.5, 1.5, cin_used).astype(np.float32), rng.normal(0, 0.5, cin_used).astype(np.float32))
+        kw['in_affine'] = aff
     if groups > 1:
         kw['groups'] = groups
     else:
@@ -105,8 +117,10 @@ def test_conv(ctx, case, precision):
     x = torch.from_numpy(np.transpose(images, (0, 3, 1, 2)).astype(np.float32) / 255.0 - 0.5)
     mid = F.relu(F.conv2d(x, torch.from_numpy(W1), torch.from_numpy(b1), padding=1))
     np.testing.assert_allclose(m.read('mid'), mid.numpy(), rtol=tol, atol=tol)
-    y = F.conv2d(mid[:, in_off:in_off + cin_used], torch.from_numpy(W2), torch.from_numpy(b2), stride=stride,
-                 padding=padv, groups=groups)
+    xin = mid[:, in_off:in_off + cin_used]
+    if aff is not None:                              # the reference order: affine first, THEN zero padding
+        xin = xin * torch.from_numpy(aff[0])[None, :, None, None] + torch.from_numpy(aff[1])[None, :, None, None]
+    y = F.conv2d(xin, torch.from_numpy(W2), torch.from_numpy(b2), stride=stride, padding=padv, groups=groups)
     if act == 1:
         y = F.relu(y)
     elif act == 2:
