@@ -494,7 +494,7 @@ def run(args):
     def ingest_leg(res):
         # -- ingest: frames come from host memory through RawVideoReader (pinned double buffers, own upload stream per
         #    pipeline), the region's per-step results are gathered in rank order on rank 0 inside the timed region
-        k = max(2 * L, min(args.steps, 60))
+        k = max(4 * L, min(max(args.steps, 48), 60))      # >= 48 steps: a 20-step region is mostly pipeline fill and drain
         gathered = []
         lock = threading.Lock()
 
