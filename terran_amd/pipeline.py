@@ -145,8 +145,17 @@ class StreamPipeline:
     """
 
     def __init__(self, devices, inflight=2, depth=2, pick_faces=all_faces, detection_kw=None, recognition_kw=None,
-                 estimation_kw=None):
+                 estimation_kw=None, switch_interval=2e-4):
+        """switch_interval: the lanes' threads spend their time inside GIL-free library calls; one that comes back must not
+        wait a whole 5 ms interpreter time slice behind another thread's result handling before it can queue its next
+        launches.  The interpreter-wide switch interval is lowered to this value while the pipeline lives (None: left alone)
+        and restored by close()."""
+        import sys
         from .facade import Detection, Recognition, Estimation
+        self._old_switch = None
+        if switch_interval is not None and sys.getswitchinterval() > switch_interval:
+            self._old_switch = sys.getswitchinterval()
+            sys.setswitchinterval(switch_interval)
         self.devices = list(devices)
         if not self.devices:
             raise ValueError('`devices` is empty')
@@ -246,3 +255,7 @@ class StreamPipeline:
                 if not any(t.is_alive() for t in lane.threads):
                     lane.close()
         self.lanes = []
+        if self._old_switch is not None:
+            import sys
+            sys.setswitchinterval(self._old_switch)
+            self._old_switch = None
