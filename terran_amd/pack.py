@@ -84,6 +84,21 @@ def split_f16_rows(packed):
     return np.ascontiguousarray(rows).view(np.float32), s
 
 
+def fold_input_affine(W, bias, scale, shift):
+    """conv3x3(pad0(scale * x + shift)) + bias  ==  conv3x3(pad0(x); W') + bias16[class of the output pixel].
+
+    The scale folds into the weights; the shift reaches an output only through the taps that are not padding, so it becomes
+    one bias per border class: per axis the pixel is the first / a middle / the last / the ONLY row (column), class =
+    4 * cy + cx (csrc/conv_igemm.hip: ta_border_class), 5 = interior.  W (cout, cin, 3, 3) float64 -> (W', bias16 (16, cout))."""
+    W = np.asarray(W, np.float64)
+    a_s, a_t = np.asarray(scale, np.float64), np.asarray(shift, np.float64)
+    T = np.einsum('ocyx,c->oyx', W, a_t)                                  # what the shift adds through tap (ky, kx)
+    b0 = np.zeros(W.shape[0]) if bias is None else np.asarray(bias, np.float64)
+    valid = ([1, 2], [0, 1, 2], [0, 1], [1])                              # in-bounds taps of a first / middle / last / only row or column
+    bias16 = np.stack([b0 + T[:, valid[cy]][:, :, valid[cx]].sum((1, 2)) for cy in range(4) for cx in range(4)])
+    return W * a_s[None, :, None, None], bias16
+
+
 class Program:
     """Accumulates tensors, ops and the weight region of one model."""
 
@@ -149,12 +164,7 @@ class Program:
         bias9 = None
         if in_affine is not None:
             assert (kh, kw, stride) == (3, 3, 1) and pad in (None, 1) and groups == 1 and out2 < 0 and scale2 is None and not pool
-            a_s, a_t = (np.asarray(v, np.float64) for v in in_affine)
-            T = np.einsum('ocyx,c->oyx', W, a_t)                          # what the shift adds through tap (ky, kx)
-            W = W * a_s[None, :, None, None]
-            b0 = np.zeros(cout) if bias is None else np.asarray(bias, np.float64)
-            valid = ([1, 2], [0, 1, 2], [0, 1], [1])                      # in-bounds taps of a first / middle / last / ONLY row or column
-            bias9 = np.stack([b0 + T[:, valid[cy]][:, :, valid[cx]].sum((1, 2)) for cy in range(4) for cx in range(4)])
+            W, bias9 = fold_input_affine(W, bias, *in_affine)
             bias = bias9[5]                                               # (middle, middle): the interior
         if groups > 1:
             assert cout % groups == 0 and cin % 32 == 0 and (cout // groups) % 128 == 0 and ch_pos is None

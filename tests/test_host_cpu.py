@@ -267,3 +267,27 @@ def test_fanout_shards_contiguously_and_keeps_order(monkeypatch):
     assert [x for x, _ in fo(np.arange(2))] == [0, 1] and len(calls) == 2              # third device idle
     with pytest.raises(ValueError):
         facade._Fanout([], make)
+
+
+def test_fold_input_affine_equals_affine_then_zero_padded_conv():
+    """pack.fold_input_affine (ArcFace's BatchNorm in front of a zero-padded conv, arcface/model.py:12-14, folded into
+    weights + border-class biases) against the reference order -- affine first, THEN zero padding -- in float64, on maps
+    with every border class: ordinary, one row, one column, a single pixel."""
+    import torch
+    import torch.nn.functional as F
+    from terran_amd import pack
+    rng = np.random.default_rng(3)
+    W, b = rng.normal(0, 0.3, (5, 4, 3, 3)), rng.normal(0, 0.2, 5)
+    sc, sh = rng.uniform(0.5, 1.5, 4), rng.normal(0, 0.7, 4)
+    Wf, b16 = pack.fold_input_affine(W, b, sc, sh)
+    assert b16.shape == (16, 5)
+    for h, w in ((6, 7), (1, 5), (4, 1), (1, 1), (2, 2), (3, 3)):
+        x = rng.normal(0, 1, (2, 4, h, w))
+        ref = F.conv2d(torch.from_numpy(x * sc[None, :, None, None] + sh[None, :, None, None]), torch.from_numpy(W),
+                       torch.from_numpy(b), padding=1).numpy()
+        raw = F.conv2d(torch.from_numpy(x), torch.from_numpy(Wf), None, padding=1).numpy()
+        cy = np.array([3 if h == 1 else (0 if y == 0 else (2 if y == h - 1 else 1)) for y in range(h)])
+        cx = np.array([3 if w == 1 else (0 if v == 0 else (2 if v == w - 1 else 1)) for v in range(w)])
+        cls = 4 * cy[:, None] + cx[None, :]
+        got = raw + np.transpose(b16[cls], (2, 0, 1))[None]
+        assert np.abs(got - ref).max() < 1e-12, (h, w)
