@@ -291,3 +291,30 @@ def test_fold_input_affine_equals_affine_then_zero_padded_conv():
         cls = 4 * cy[:, None] + cx[None, :]
         got = raw + np.transpose(b16[cls], (2, 0, 1))[None]
         assert np.abs(got - ref).max() < 1e-12, (h, w)
+
+
+def test_split_f16_rows_carry_22_bits_and_a_power_of_two_scale():
+    """pack.split_f16_rows: weights x 2^s as [hi | lo] half floats; (hi + lo) 2^-s reproduces every weight within 2^-16 of
+    the layer's largest to 2^-21 relative, nothing overflows, and the detector's mixed-mode program gives the refiner's
+    64-channel tensors the half-split format while everything the float32 base touches stays float32."""
+    from terran_amd import pack, weights
+    rng = np.random.default_rng(5)
+    w = (rng.normal(0, 0.04, (3, 64, 32)) * np.exp(rng.normal(0, 2.0, (3, 64, 1)))).astype(np.float32)   # rows of very different scale
+    rows, s = pack.split_f16_rows(w)
+    h16 = rows.view(np.float16).reshape(3, 64, 64)
+    hi, lo = h16[..., :32].astype(np.float64), h16[..., 32:].astype(np.float64)
+    assert np.isfinite(hi).all() and np.abs(hi).max() < 2.0 ** 15 and 2.0 ** 13 <= np.abs(w).max() * 2.0 ** s < 2.0 ** 14
+    back = (hi + lo) * 2.0 ** -s
+    big = np.abs(w) >= np.abs(w).max() * 2.0 ** -16
+    assert big.mean() > 0.8
+    assert (np.abs(back - w)[big] <= np.abs(w)[big] * 2.0 ** -21).all()
+    assert np.abs(back - w).max() <= np.abs(w).max() * 2.0 ** -23           # absolute error: one rounding of hi + lo at the top of the range
+    P = pack.pack_retinaface(weights.make_retinaface_state(), 'f16x3')
+    fmt = P.tensor_formats()
+    precs = {}
+    for op in P.ops:
+        precs.setdefault(op['type'], set()).add(op['prec'])
+    assert precs[pack.OP_CONV] == {3} and precs[pack.OP_DWPW] == {0, 3} and precs[pack.OP_RFSTEM] == {0}
+    split = [t for t, f in enumerate(fmt) if f == pack.FMT_SPLIT16]
+    assert len(split) == 5 and all(P.tensors[t][0] == 64 for t in split)     # p32, s16, p16, s8, p8
+    assert set(pack.pack_retinaface(weights.make_retinaface_state(), 'bf16x3').tensor_formats()) == {pack.FMT_F32}
