@@ -1433,6 +1433,9 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)((walk.y0 << pl) * p.stride) * p.in_row +
                         (size_t)((walk.x0 << pl) * p.stride) * p.in_pix + p.in_off0 + in_ch;
     const char* b_base = (const char*)(p.in + off0);
+    ta_k_walk wb(p, s_begin);
+    // every pixel row's DMA of slab 0 goes out as soon as its address is known: the index arithmetic of the later rows
+    // (two reciprocal divisions each) then runs under the flight time of the earlier ones instead of in front of them all
 #pragma unroll
     for (int q = QA; q < NI; ++q) {
       const int d = (q * NP + pw) * 8 + (lane >> 3) - BN;   // pixel row of the stage image
@@ -1446,15 +1449,16 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row + (size_t)(x * p.stride) * p.in_pix +
                          p.in_off0 + in_ch;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
+      if (!p.late_b) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + (q * NP + pw) * 256);      // slab 0 -> stage 0
     }
-    ta_k_walk wb(p, s_begin);
+    if (!p.late_b) wb.advance();
     auto issue_b = [&](int stage) {                 // pixel rows of the next slab in K order
 #pragma unroll
       for (int q = QA; q < NI; ++q) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
       wb.advance();
     };
-    if (wave == NC) TA_STAMP(9);                    // producer: addresses ready
-    issue_b(0);
+    if (wave == NC) TA_STAMP(9);                    // producer: addresses ready, slab 0 issued
+    if (p.late_b) issue_b(0);                        // tools (TA_CONV_LATE_B): the round-2 order, all addresses first
     if (S > 1) issue_b(1);
     if (wave == NC) TA_STAMP(10);                    // producer: first slabs issued
     int stage = 2;                                  // stage the next issued slab goes to
@@ -1691,6 +1695,8 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     q.fast_drain = ok ? 1 : 0;
     if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;     // slot 15: launches whose epilogue ran the specialised drain
   }
+  static const bool late_b = getenv("TA_CONV_LATE_B") != nullptr;             // tools: A/B of the early slab-0 pixel-row DMAs
+  q.late_b = late_b ? 1 : 0;
   static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
   q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
   {

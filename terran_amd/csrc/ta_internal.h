@@ -266,6 +266,7 @@ struct ta_conv_launch {
   int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results)
   const float* bias9;                          // border-class biases [16][coutp] of a conv with a folded input affine (nullptr: none)
+  int late_b;                                  // tools only (TA_CONV_LATE_B): slab 0's pixel-row DMAs after ALL addresses are computed
   float w_unscale;                             // sums are multiplied by this before the bias (2^-wscale_log2; 1 outside f16x3)
   int* range_flag;                             // set to 1 by an epilogue that writes |x| > 65504 into a TA_FMT_SPLIT16 tensor
 };
