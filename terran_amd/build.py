@@ -99,7 +99,41 @@ def build(force=False, verbose=False):
             raise RuntimeError('link failed:\n%s' % r.stdout.decode(errors='replace'))
         with open(STAMP, 'w') as fh:             # lib.load() refuses a binary that does not match the sources beside it
             fh.write(source_hash() + '\n')
+    build_pyresults(force, verbose)
     return LIB
+
+
+def build_pyresults(force=False, verbose=False):
+    """The small CPython module that builds the reference's list-of-dicts results (csrc/pyresults.c); gcc, no GPU code.
+    Optional: results.py falls back to a Python comprehension when it cannot be built."""
+    import sysconfig
+    src = os.path.join(CSRC, 'pyresults.c')
+    out = os.path.join(HERE, '_pyresults' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+    try:
+        import numpy
+        inc = [sysconfig.get_paths()['include'], numpy.get_include()]
+        if not os.path.exists(os.path.join(inc[0], 'Python.h')):
+            return None
+        want = _unit_hash(src, [], ['gcc', '-O2'] + inc)
+        try:
+            with open(out + '.stamp') as fh:
+                have = fh.read().strip()
+        except OSError:
+            have = None
+        if force or have != want or not os.path.exists(out):
+            cmd = ['gcc', '-O2', '-shared', '-fPIC'] + ['-I' + i for i in inc] + [src, '-o', out]
+            if verbose:
+                print(' '.join(cmd))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                if verbose:
+                    print(r.stdout.decode(errors='replace'))
+                return None
+            with open(out + '.stamp', 'w') as fh:
+                fh.write(want + '\n')
+        return out
+    except Exception:                                 # noqa: BLE001  (optional component)
+        return None
 
 
 def build_probes(force=False):

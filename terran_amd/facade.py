@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import lib, runtime
+from . import lib, results, runtime
 from .checkpoint import get_class_for_checkpoint
 from .shard import shard_bounds
 
@@ -204,12 +204,7 @@ class Detection:
             # same float32 element-wise arithmetic as the reference's per-face code (face/detection/__init__.py:59-84)
             b = np.around(boxes / scales).astype(np.int32)
             l = np.around(lmks / scales).astype(np.int32)
-            out, o = [], 0
-            for c in counts:
-                c = int(c)
-                out.append([{'bbox': x, 'landmarks': y, 'score': z}
-                            for x, y, z in zip(b[o:o + c], l[o:o + c], scores[o:o + c])])
-                o += c
+            out = results.detections(counts, b, l, scores)
             return out[0] if expanded else out
         # un-pad and un-scale one image at a time (same element-wise arithmetic and dtypes as the
         # reference's per-face code, face/detection/__init__.py:59-84,141-176), then hand out row views

@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import lib, pack, runtime
+from . import lib, pack, results, runtime
 
 
 class RetinaFace(runtime.RangeFallback):
@@ -46,14 +46,7 @@ class RetinaFace(runtime.RangeFallback):
 
     def call_frames(self, frames, threshold=0.5):
         """frames: lib.Frames (N,H,W,3) at network resolution, resident in HBM."""
-        counts, boxes, lmks, scores = self.detect_arrays(frames, threshold)
-        out, o = [], 0
-        for c in counts:
-            c = int(c)
-            out.append([{'bbox': b, 'landmarks': l, 'score': s}
-                        for b, l, s in zip(boxes[o:o + c], lmks[o:o + c], scores[o:o + c])])
-            o += c
-        return out
+        return results.detections(*self.detect_arrays(frames, threshold))
 
     def call(self, images, threshold=0.5):
         """images: (N,H,W,3) uint8 RGB ndarray -> list[N] of list[{'bbox','landmarks','score'}] in

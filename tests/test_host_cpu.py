@@ -318,3 +318,33 @@ def test_split_f16_rows_carry_22_bits_and_a_power_of_two_scale():
     split = [t for t, f in enumerate(fmt) if f == pack.FMT_SPLIT16]
     assert sorted(P.tensors[t][0] for t in split) == [64] * 5 + [256]        # p32, s16, p16, s8, p8 + the stride-32 feature (read by its lateral only)
     assert set(pack.pack_retinaface(weights.make_retinaface_state(), 'bf16x3').tensor_formats()) == {pack.FMT_F32}
+
+
+def test_c_result_builder_yields_the_comprehensions_objects():
+    """terran_amd.results.detections (csrc/pyresults.c when built, else the comprehension): the reference's list[N] of
+    list[{'bbox', 'landmarks', 'score'}] (retinaface/wrapper.py:228-236) as row VIEWS into the packed arrays + numpy
+    float32 scalars -- same keys in the same order, same dtypes, same aliasing as the Python comprehension."""
+    from terran_amd import results
+    rng = np.random.default_rng(2)
+    counts = np.array([3, 0, 5, 1], np.int32)
+    T = int(counts.sum())
+    boxes = rng.random((T + 2, 4)).astype(np.float32)
+    lmks = rng.random((T + 2, 5, 2)).astype(np.float32)
+    scores = rng.random(T + 2).astype(np.float32)
+    for b, l in ((boxes, lmks), (np.around(boxes * 50).astype(np.int32), np.around(lmks * 50).astype(np.int32))):
+        a = results.detections_py(counts, b[:T], l[:T], scores[:T])
+        c = results.detections(counts, b[:T], l[:T], scores[:T])
+        assert [len(x) for x in c] == [3, 0, 5, 1] == [len(x) for x in a]
+        for p, q in zip(a, c):
+            for x, y in zip(p, q):
+                assert list(y) == ['bbox', 'landmarks', 'score'] == list(x)
+                assert y['bbox'].shape == (4,) and y['landmarks'].shape == (5, 2) and y['bbox'].dtype == b.dtype
+                assert np.array_equal(x['bbox'], y['bbox']) and np.array_equal(x['landmarks'], y['landmarks'])
+                assert type(y['score']) is np.float32 and y['score'] == x['score']
+        c[2][1]['bbox'][0] = 77                                   # a view into the packed array, like the comprehension's rows
+        assert b[4, 0] == 77
+    if results._pyresults is not None:
+        with pytest.raises(ValueError):
+            results.detections(counts.astype(np.int64), boxes, lmks, scores)
+        with pytest.raises(ValueError):
+            results.detections(np.array([T + 3], np.int32), boxes, lmks, scores)
