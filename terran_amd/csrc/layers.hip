@@ -183,98 +183,233 @@ int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, i
 // uint8 RGB frame -> BGR float 0..255 -> conv3x3 s2 p1 (3 -> 8) + BN + ReLU -> depthwise 3x3 p1 (8) + BN + ReLU ->
 // 1x1 (8 -> 16) + BN + ReLU, written once as a 16-channel float tensor at half resolution.  Unfused this is four
 // launches that stream a 4-channel float copy of the frames and two 8-channel maps through HBM (0.37 ms per 32 frames at
-// 416 x 739); here a workgroup builds an 18 x 18 x 8 tile of the stride-2 map in LDS (zero outside the map: the
-// depthwise conv's own padding) and every thread finishes one output pixel.  All float32 FMAs, taps in (ky, kx, c) order.
-// weights: [stem W 8x27 (o, c_bgr, ky, kx)] [stem b 8] [dw W 9x8 (tap, c)] [dw b 8] [pw W 16x8 (o, c)] [pw b 16] = 448 floats
-#define RFS_T 16
-#define RFS_IN (2 * (RFS_T + 2) + 1)          // input rows / columns under an (RFS_T + 2)^2 tile of the stride-2 map
+// 416 x 739).  All float32 FMAs, taps in (ky, kx, c) order.
+//
+// A workgroup finishes a 14 x 62 tile of the output.  The 448 weights are kernel arguments, i.e. scalar loads, and it is
+// their latency that bounded the first version of this kernel (one pixel per thread, ~110 waits on a scalar load for 830
+// FMAs, bytes addressed with an integer division each: 154 us per 32 frames at 416 x 739 with the vector ALU 10 % busy).
+// Here every thread works on FOUR horizontally adjacent pixels per weight it fetches, and the weights arrive in blocks of
+// 24 .. 72 (loops / scheduling barriers keep the compiler from fetching all 448 first and spilling them into lanes):
+//   1. the 33-row x 129-pixel window of the frame goes to LDS as the BYTES they are, copied with aligned dword loads
+//      (bytes outside the frame = the conv's zero padding are masked to 0; each row keeps its own misalignment 0..3);
+//   2. thread (ty, j) builds pixels 4j..4j+3 of row ty of the 16 x 64 x 8 tile of the stride-2 map from 3 x 27 window bytes
+//      (4 x ds_read_b64 + 7 x v_alignbyte per row; zero outside the map: the depthwise conv's own padding);
+//   3. thread (py, g) finishes output pixels 4g..4g+3 of row py: depthwise 3x3 from 3 x 6 tile pixels, then the 1x1;
+//   4. the 14 x 62 x 16 results cross LDS once more so that a store instruction writes 1 KB of consecutive bytes (from the
+//      registers a lane's 16 bytes are 256 bytes from its neighbour's: measured 33 us of the kernel's 98).
+// The tile is kept as two planes of 4 channels with a 16-byte pad after every 4 pixels: a thread's 16-byte accesses are
+// 80 bytes from its neighbour's -- conflict-free for the 16-lane groups LDS serves a b128 access in; the output staging
+// XORs a thread's chunk index with its number for the same reason.
+// weights as passed: [stem W 27x8 (tap = ky, kx, c_bgr; o)] [stem b 8] [dw W 9x8 (tap, c)] [dw b 8] [pw W 16x8 (o, c)] [pw b 16]
+// = 448 floats (the blob holds the stem conv as (o, c, ky, kx): the launcher transposes it).
+// `frames` is 4-byte aligned and readable up to the next multiple of 4 beyond the last frame (frames_alloc rounds up).
+#define RFS_TY 14
+#define RFS_TX 62
+#define RFS_CY (RFS_TY + 2)                   // rows / columns of the stride-2 map under an output tile
+#define RFS_CX (RFS_TX + 2)
+#define RFS_IY (2 * RFS_CY + 1)               // frame rows under those
+#define RFS_IXB ((2 * RFS_CX + 1) * 3)        // ... and bytes per row (387)
+#define RFS_DW ((RFS_IXB + 3 + 3) / 4)        // aligned dwords that cover them at any misalignment (98)
+#define RFS_PITCH 100                         // dwords per window row in LDS
+#define RFS_TPITCH 84                         // 16-byte slots per tile row and plane: pixel x lives in slot x + x / 4
+#define RFS_PIX_SLOTS (RFS_IY * RFS_PITCH / 4)
+#define RFS_LDS_SLOTS (RFS_PIX_SLOTS + 2 * RFS_CY * RFS_TPITCH)
+#define RFS_OROW (RFS_TX * 4)                 // 16-byte chunks per output tile row (248)
+#define RFS_OPITCH 256                        // ... and slots per row of the output staging (16 threads x 16 chunks)
+#define RFS_SLOTS (RFS_TY * RFS_OPITCH > RFS_LDS_SLOTS ? RFS_TY * RFS_OPITCH : RFS_LDS_SLOTS)
+static_assert(RFS_IY * RFS_PITCH % 4 == 0, "tile stays 16-byte aligned");
 struct rf_stem_weights {
   float v[448];                               // passed BY VALUE: wave-uniform reads become scalar loads, FMAs take SGPR operands
 };
-__global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int H, int W, const rf_stem_weights wt, float* out, int Ho,
-                                                       int Wo, int o_img, int o_row, int o_pix, int o_off0) {
-  __shared__ uint8_t pix[RFS_IN * RFS_IN * 3 + 3];
-  __shared__ float tile[(RFS_T + 2) * (RFS_T + 2) * 8];
+__global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int H, int W, const rf_stem_weights wt,
+                                                       float* out, int Ho, int Wo, int o_img, int o_row, int o_pix, int o_off0) {
+  __shared__ __attribute__((aligned(16))) f32x4 lds4[RFS_SLOTS];       // 56 KB: two workgroups per CU
+  unsigned* pix = (unsigned*)lds4;
+  f32x4* tile = lds4 + RFS_PIX_SLOTS;
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  const int ty0 = blockIdx.y * RFS_T, tx0 = blockIdx.x * RFS_T;
-  const uint8_t* fr = frames + (size_t)img * H * W * 3;
-  // input window: rows 2 (ty0 - 1) - 1 ..., zero outside the frame (the conv's padding)
+  const int ty0 = blockIdx.y * RFS_TY, tx0 = blockIdx.x * RFS_TX;
   const int iy0 = 2 * (ty0 - 1) - 1, ix0 = 2 * (tx0 - 1) - 1;
-  for (int i = tid; i < RFS_IN * RFS_IN * 3; i += 256) {
-    const int r = i / (RFS_IN * 3), cb = i - r * (RFS_IN * 3);
-    const int iy = iy0 + r, ix = ix0 + cb / 3;
-    pix[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? fr[((size_t)iy * W + ix) * 3 + cb % 3] : (uint8_t)0;
-  }
-  __syncthreads();
-  const float* sW = wt.v;          // [8][27]
-  const float* sB = wt.v + 216;
-  for (int idx = tid; idx < (RFS_T + 2) * (RFS_T + 2); idx += 256) {
-    const int ty = idx / (RFS_T + 2), tx = idx - ty * (RFS_T + 2);
-    const int sy = ty0 - 1 + ty, sx = tx0 - 1 + tx;
-    float acc[8];
-    if (sy < 0 || sy >= Ho || sx < 0 || sx >= Wo) {
+  const int Wb = W * 3;
+  const uint8_t* imgp = frames + (size_t)img * H * Wb;
+  // misalignment of frame row 0's first window byte, as a non-negative number (ix0 >= -3)
+  const int mis_img = (int)(((size_t)imgp + 12 + ix0 * 3) & 3);
+  // 1. window rows as bytes: two rows per pass (waves 0-1 / 2-3), thread = one aligned dword.  All of a thread's loads
+  //    are issued before the first one is waited for.
+  {
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int k = tid & 127;
+    constexpr int NR = (RFS_IY + 1) / 2;
+    unsigned v[NR];
+    if (k < RFS_DW) {
 #pragma unroll
-      for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-    } else {
+      for (int i = 0; i < NR; ++i) {
+        const int r = half + 2 * i;
+        const int iy = iy0 + r;
+        const bool row_ok = r < RFS_IY && iy >= 0 && iy < H;          // wave-uniform
+        const int iyc = row_ok ? iy : 0;
+        const int mis = (mis_img + iyc * Wb) & 3;                      // of this row's first window byte
+        const int fb0 = ix0 * 3 - mis + 4 * k;                         // frame-row byte index of this dword's byte 0
+        const uint8_t* rowp = imgp + (size_t)iyc * Wb;                 // uniform; rowp + fb0 is 4-byte aligned
+        v[i] = 0;
+        if (row_ok && fb0 > -4 && fb0 < Wb) v[i] = *(const unsigned*)(rowp + fb0);
+      }
 #pragma unroll
-      for (int o = 0; o < 8; ++o) acc[o] = sB[o];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const uint8_t* px = pix + ((2 * ty + ky) * RFS_IN + 2 * tx + kx) * 3;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float v = (float)px[2 - c];                 // network channel c of BGR = frame channel 2 - c
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(v, sW[o * 27 + c * 9 + ky * 3 + kx], acc[o]);
-          }
-        }
-#pragma unroll
-      for (int o = 0; o < 8; ++o) acc[o] = acc[o] > 0.f ? acc[o] : 0.f;
-    }
-    *(f32x4*)(tile + idx * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-    *(f32x4*)(tile + idx * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-  }
-  __syncthreads();
-  const int py = tid / RFS_T, px_ = tid - py * RFS_T;
-  const int oy = ty0 + py, ox = tx0 + px_;
-  if (oy >= Ho || ox >= Wo) return;
-  const float* dW = wt.v + 224;    // [9][8]
-  const float* dB = wt.v + 296;
-  const float* pW = wt.v + 304;    // [16][8]
-  const float* pB = wt.v + 432;
-  float d[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) d[c] = dB[c];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float* t = tile + ((py + ky) * (RFS_T + 2) + px_ + kx) * 8;
-      const f32x4 t0 = *(const f32x4*)t, t1 = *(const f32x4*)(t + 4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        d[c] = __builtin_fmaf(t0[c], dW[(ky * 3 + kx) * 8 + c], d[c]);
-        d[4 + c] = __builtin_fmaf(t1[c], dW[(ky * 3 + kx) * 8 + 4 + c], d[4 + c]);
+      for (int i = 0; i < NR; ++i) {
+        const int r = half + 2 * i;
+        if (r >= RFS_IY) continue;
+        const int iy = iy0 + r;
+        const bool row_ok = iy >= 0 && iy < H;
+        const int mis = (mis_img + (row_ok ? iy : 0) * Wb) & 3;
+        const int fb0 = ix0 * 3 - mis + 4 * k;
+        int lo = -fb0, hi = Wb - fb0;                                  // bytes [lo, hi) of the dword are inside the frame row
+        lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+        hi = hi > 4 ? 4 : (hi < 0 ? 0 : hi);
+        const unsigned mlo = lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo);
+        const unsigned mhi = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
+        pix[r * RFS_PITCH + k] = v[i] & mlo & mhi;
       }
     }
+  }
+  __syncthreads();
+  // 2. conv3x3 s2 (3 -> 8) + ReLU: thread = (row ty, pixels 4j .. 4j+3)
+  {
+    const float* sW = wt.v;          // [27][8]
+    const float* sB = wt.v + 216;
+    const int ty = tid >> 4, j = tid & 15;
+    const int sy = ty0 - 1 + ty;
+    const bool srow_ok = sy >= 0 && sy < Ho;
+    float acc[4][8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) d[c] = d[c] > 0.f ? d[c] : 0.f;
-  float* o = out + (size_t)img * o_img + (size_t)oy * o_row + (size_t)ox * o_pix + o_off0;
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 r;
+      for (int o = 0; o < 8; ++o) acc[p][o] = sB[o];
+#pragma nounroll
+    for (int ky = 0; ky < 3; ++ky) {            // a real loop: 72 weights (scalar registers) per trip, see above
+      const int r = 2 * ty + ky;
+      const int iy = iy0 + r;
+      const int mis = (mis_img + ((iy >= 0 && iy < H) ? iy : 0) * Wb) & 3;
+      const unsigned* row = pix + r * RFS_PITCH + 6 * j;          // window bytes 24 j ... start `mis` bytes into this dword
+      unsigned d[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int oc = q * 4 + e;
-      float a = pB[oc];
+      for (int q = 0; q < 4; ++q) {
+        const uint2 t = *(const uint2*)(row + 2 * q);
+        d[2 * q] = t.x;
+        d[2 * q + 1] = t.y;
+      }
+      float f[28];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) a = __builtin_fmaf(d[c], pW[oc * 8 + c], a);
-      r[e] = a > 0.f ? a : 0.f;
+      for (int q = 0; q < 7; ++q) {
+        const unsigned u = __builtin_amdgcn_alignbyte(d[q + 1], d[q], (unsigned)mis);
+        f[4 * q] = (float)(u & 255u);
+        f[4 * q + 1] = (float)((u >> 8) & 255u);
+        f[4 * q + 2] = (float)((u >> 16) & 255u);
+        f[4 * q + 3] = (float)(u >> 24);
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* w = sW + ((ky * 3 + kx) * 3 + c) * 8;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float v = f[(2 * p + kx) * 3 + 2 - c];        // network channel c of BGR = frame channel 2 - c
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[p][o] = __builtin_fmaf(v, w[o], acc[p][o]);
+          }
+        }
     }
-    *(f32x4*)(o + q * 4) = r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int sx = tx0 - 1 + 4 * j + p;
+      const bool in_map = srow_ok && sx >= 0 && sx < Wo;
+      f32x4 a, b;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        a[o] = in_map && acc[p][o] > 0.f ? acc[p][o] : 0.f;
+        b[o] = in_map && acc[p][4 + o] > 0.f ? acc[p][4 + o] : 0.f;
+      }
+      tile[ty * RFS_TPITCH + 5 * j + p] = a;
+      tile[(RFS_CY + ty) * RFS_TPITCH + 5 * j + p] = b;
+    }
+  }
+  __syncthreads();
+  // 3. depthwise 3x3 (8) + ReLU, 1x1 (8 -> 16) + ReLU: thread = (row py, pixels 4g .. 4g+3)
+  const int py = tid >> 4, g = tid & 15;
+  const bool active = py < RFS_TY;
+  float r[4][16];
+  if (active) {
+    const float* dW = wt.v + 224;    // [9][8]
+    const float* dB = wt.v + 296;
+    const float* pW = wt.v + 304;    // [16][8]
+    const float* pB = wt.v + 432;
+    float d[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[p][c] = dB[c];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      f32x4 ta[6], tb[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int x = 4 * g + i;                                   // <= 65: slot x + x / 4 <= 81 (64, 65: never written,
+        ta[i] = tile[(py + ky) * RFS_TPITCH + x + (x >> 2)];       //  read only for pixels 62, 63 that are not stored)
+        tb[i] = tile[(RFS_CY + py + ky) * RFS_TPITCH + x + (x >> 2)];
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            d[p][c] = __builtin_fmaf(ta[p + kx][c], dW[(ky * 3 + kx) * 8 + c], d[p][c]);
+            d[p][4 + c] = __builtin_fmaf(tb[p + kx][c], dW[(ky * 3 + kx) * 8 + 4 + c], d[p][4 + c]);
+          }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[p][c] = d[p][c] > 0.f ? d[p][c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // output channels 4q .. 4q+3: 32 weights per block
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oc = q * 4 + e;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[p][oc] = pB[oc];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) r[p][oc] = __builtin_fmaf(d[p][c], pW[oc * 8 + c], r[p][oc]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[p][oc] = r[p][oc] > 0.f ? r[p][oc] : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();                                // every tile read is done: window + tile become the output staging
+  // 4. staging: row py, chunk (16 bytes) c of thread g at 16 g + (c ^ g)
+  if (active) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = p * 4 + q;
+        lds4[py * RFS_OPITCH + 16 * g + (c ^ g)] = f32x4{r[p][4 * q], r[p][4 * q + 1], r[p][4 * q + 2], r[p][4 * q + 3]};
+      }
+  }
+  __syncthreads();
+  float* obase = out + (size_t)img * o_img + o_off0;
+#pragma unroll 2
+  for (int f = tid; f < RFS_TY * RFS_OROW; f += 256) {
+    const int row = f / RFS_OROW, c = f - row * RFS_OROW;
+    const int oy = ty0 + row, ox = tx0 + (c >> 2);
+    if (oy >= Ho || ox >= Wo) continue;
+    const int gg = c >> 4;
+    const f32x4 v = lds4[row * RFS_OPITCH + 16 * gg + ((c & 15) ^ gg)];
+    *(f32x4*)(obase + (size_t)oy * o_row + (size_t)ox * o_pix + (c & 3) * 4) = v;
   }
 }
 
@@ -282,12 +417,17 @@ int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w
   if (!frames_dev || !weights_host || out.c != 16 || out.fmt != TA_FMT_F32 || out.h != (h + 1) / 2 || out.w != (w + 1) / 2 || out.n < n)
     return ta_fail(ctx, TA_E_INVALID, "rfstem: destination tensor mismatch");
   if (n <= 0) return TA_OK;
+  if ((uintptr_t)frames_dev & 3)
+    return ta_fail(ctx, TA_E_INVALID, "rfstem: the frames must be 4-byte aligned");
   ta_prof_scope scope(ctx, 0, 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w);   // the two dense convs (depthwise MACs are not counted anywhere)
   ctx->cur_flops = 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w;
   ctx->note_kernel("rf_stem_kernel");
   rf_stem_weights wt;                                                   // 1.8 KB of kernel arguments
   memcpy(wt.v, weights_host, sizeof(wt.v));
-  hipLaunchKernelGGL(rf_stem_kernel, dim3((out.w + RFS_T - 1) / RFS_T, (out.h + RFS_T - 1) / RFS_T, n), dim3(256), 0, ctx->stream,
+  for (int o = 0; o < 8; ++o)                                           // (o, c, ky, kx) -> (ky, kx, c; o)
+    for (int c = 0; c < 3; ++c)
+      for (int t = 0; t < 9; ++t) wt.v[(t * 3 + c) * 8 + o] = weights_host[o * 27 + c * 9 + t];
+  hipLaunchKernelGGL(rf_stem_kernel, dim3((out.w + RFS_TX - 1) / RFS_TX, (out.h + RFS_TY - 1) / RFS_TY, n), dim3(256), 0, ctx->stream,
                      frames_dev, h, w, wt, out.dev, out.h, out.w, (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c,
                      out.c, (int)out.off(0, 0, 0));
   TA_HIP(ctx, hipGetLastError());

@@ -362,7 +362,7 @@ int ta_frames_alloc(ta_ctx* ctx, int n, int h, int w, ta_frames** out) {
 static int frames_alloc(ta_ctx* ctx, int n, int h, int w, bool zero, ta_frames** out) {
   if (!ctx || !out || n < 0 || h <= 0 || w <= 0) return ta_fail(ctx, TA_E_INVALID, "frames_alloc: bad shape");
   ta_frames* f = new ta_frames{ctx, n, h, w, nullptr};
-  size_t bytes = (size_t)n * h * w * 3;
+  size_t bytes = ((size_t)n * h * w * 3 + 15) & ~(size_t)15;      // kernels read the frames in aligned dwords (rf_stem_kernel)
   if (bytes == 0) bytes = 16;
   {
     std::lock_guard<std::mutex> lock(ctx->frame_cache_mu);
