@@ -188,8 +188,10 @@ int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, i
 // A workgroup finishes a 14 x 62 tile of the output.  The 448 weights are kernel arguments, i.e. scalar loads, and it is
 // their latency that bounded the first version of this kernel (one pixel per thread, ~110 waits on a scalar load for 830
 // FMAs, bytes addressed with an integer division each: 154 us per 32 frames at 416 x 739 with the vector ALU 10 % busy).
-// Here every thread works on FOUR horizontally adjacent pixels per weight it fetches, and the weights arrive in blocks of
-// 24 .. 72 (loops / scheduling barriers keep the compiler from fetching all 448 first and spilling them into lanes):
+// Here every thread works on FOUR horizontally adjacent pixels per weight it fetches, the weights arrive in blocks of
+// 32 .. 80 (real loops keep the compiler from fetching all 448 first and spilling them into lanes) and every FMA is one
+// half of a v_pk_fma_f32: 73 us (PMC: 1.9 k vector instructions per wave, vector ALU busy half of the time; with two
+// workgroups = 8 waves per CU -- 56 KB of LDS each -- the rest is latency the two cannot hide for each other):
 //   1. the 33-row x 129-pixel window of the frame goes to LDS as the BYTES they are, copied with aligned dword loads
 //      (bytes outside the frame = the conv's zero padding are masked to 0; each row keeps its own misalignment 0..3);
 //   2. thread (ty, j) builds pixels 4j..4j+3 of row ty of the 16 x 64 x 8 tile of the stride-2 map from 3 x 27 window bytes
@@ -200,9 +202,10 @@ int ta_launch_preprocess(ta_ctx* ctx, int mode, const uint8_t* src_dev, int n, i
 // The tile is kept as two planes of 4 channels with a 16-byte pad after every 4 pixels: a thread's 16-byte accesses are
 // 80 bytes from its neighbour's -- conflict-free for the 16-lane groups LDS serves a b128 access in; the output staging
 // XORs a thread's chunk index with its number for the same reason.
-// weights as passed: [stem W 27x8 (tap = ky, kx, c_bgr; o)] [stem b 8] [dw W 9x8 (tap, c)] [dw b 8] [pw W 16x8 (o, c)] [pw b 16]
-// = 448 floats (the blob holds the stem conv as (o, c, ky, kx): the launcher transposes it).
+// weights as passed: [stem W 27x8 (tap = ky, kx, c_bgr; o)] [stem b 8] [dw W 9x8 (tap, c)] [dw b 8] [pw W 8x16 (c, o)] [pw b 16]
+// = 448 floats (the blob holds the stem conv as (o, c, ky, kx) and the 1x1 as (o, c): the launcher transposes them).
 // `frames` is 4-byte aligned and readable up to the next multiple of 4 beyond the last frame (frames_alloc rounds up).
+typedef float rfs_f32x2 __attribute__((ext_vector_type(2)));
 #define RFS_TY 14
 #define RFS_TX 62
 #define RFS_CY (RFS_TY + 2)                   // rows / columns of the stride-2 map under an output tile
@@ -235,39 +238,50 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
   // misalignment of frame row 0's first window byte, as a non-negative number (ix0 >= -3)
   const int mis_img = (int)(((size_t)imgp + 12 + ix0 * 3) & 3);
   // 1. window rows as bytes: two rows per pass (waves 0-1 / 2-3), thread = one aligned dword.  All of a thread's loads
-  //    are issued before the first one is waited for.
+  //    are issued before the first one is waited for.  Only tiles on the frame's left / right edge mask bytes.
+  const int wb3 = Wb & 3;
   {
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int k = tid & 127;
     constexpr int NR = (RFS_IY + 1) / 2;
     unsigned v[NR];
+    const bool x_inside = ix0 >= 0 && ix0 * 3 + RFS_IXB + 3 <= Wb;      // every dword of every row lies inside its frame row
     if (k < RFS_DW) {
+      const int fbk = ix0 * 3 + 4 * k;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int r = half + 2 * i;
         const int iy = iy0 + r;
         const bool row_ok = r < RFS_IY && iy >= 0 && iy < H;          // wave-uniform
         const int iyc = row_ok ? iy : 0;
-        const int mis = (mis_img + iyc * Wb) & 3;                      // of this row's first window byte
-        const int fb0 = ix0 * 3 - mis + 4 * k;                         // frame-row byte index of this dword's byte 0
+        const int mis = (mis_img + (iyc & 3) * wb3) & 3;               // of this row's first window byte
+        const int fb0 = fbk - mis;                                     // frame-row byte index of this dword's byte 0
         const uint8_t* rowp = imgp + (size_t)iyc * Wb;                 // uniform; rowp + fb0 is 4-byte aligned
         v[i] = 0;
-        if (row_ok && fb0 > -4 && fb0 < Wb) v[i] = *(const unsigned*)(rowp + fb0);
+        if (row_ok && (x_inside || (fb0 > -4 && fb0 < Wb))) v[i] = *(const unsigned*)(rowp + fb0);
       }
+      if (x_inside) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int r = half + 2 * i;
-        if (r >= RFS_IY) continue;
-        const int iy = iy0 + r;
-        const bool row_ok = iy >= 0 && iy < H;
-        const int mis = (mis_img + (row_ok ? iy : 0) * Wb) & 3;
-        const int fb0 = ix0 * 3 - mis + 4 * k;
-        int lo = -fb0, hi = Wb - fb0;                                  // bytes [lo, hi) of the dword are inside the frame row
-        lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
-        hi = hi > 4 ? 4 : (hi < 0 ? 0 : hi);
-        const unsigned mlo = lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo);
-        const unsigned mhi = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
-        pix[r * RFS_PITCH + k] = v[i] & mlo & mhi;
+        for (int i = 0; i < NR; ++i) {
+          const int r = half + 2 * i;
+          if (r < RFS_IY) pix[r * RFS_PITCH + k] = v[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int r = half + 2 * i;
+          if (r >= RFS_IY) continue;
+          const int iy = iy0 + r;
+          const bool row_ok = iy >= 0 && iy < H;
+          const int mis = (mis_img + ((row_ok ? iy : 0) & 3) * wb3) & 3;
+          const int fb0 = fbk - mis;
+          int lo = -fb0, hi = Wb - fb0;                                // bytes [lo, hi) of the dword are inside the frame row
+          lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+          hi = hi > 4 ? 4 : (hi < 0 ? 0 : hi);
+          const unsigned mlo = lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo);
+          const unsigned mhi = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
+          pix[r * RFS_PITCH + k] = v[i] & mlo & mhi;
+        }
       }
     }
   }
@@ -279,16 +293,16 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
     const int ty = tid >> 4, j = tid & 15;
     const int sy = ty0 - 1 + ty;
     const bool srow_ok = sy >= 0 && sy < Ho;
-    float acc[4][8];
+    rfs_f32x2 acc[4][4];                          // [pixel][pair of output channels]: v_pk_fma_f32 throughout
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int o = 0; o < 8; ++o) acc[p][o] = sB[o];
+      for (int o = 0; o < 4; ++o) acc[p][o] = rfs_f32x2{sB[2 * o], sB[2 * o + 1]};
 #pragma nounroll
     for (int ky = 0; ky < 3; ++ky) {            // a real loop: 72 weights (scalar registers) per trip, see above
       const int r = 2 * ty + ky;
       const int iy = iy0 + r;
-      const int mis = (mis_img + ((iy >= 0 && iy < H) ? iy : 0) * Wb) & 3;
+      const int mis = (mis_img + (((iy >= 0 && iy < H) ? iy : 0) & 3) * wb3) & 3;
       const unsigned* row = pix + r * RFS_PITCH + 6 * j;          // window bytes 24 j ... start `mis` bytes into this dword
       unsigned d[8];
 #pragma unroll
@@ -314,20 +328,29 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             const float v = f[(2 * p + kx) * 3 + 2 - c];        // network channel c of BGR = frame channel 2 - c
+            const rfs_f32x2 vv = {v, v};
 #pragma unroll
-            for (int o = 0; o < 8; ++o) acc[p][o] = __builtin_fmaf(v, w[o], acc[p][o]);
+            for (int o = 0; o < 4; ++o) acc[p][o] = __builtin_elementwise_fma(vv, rfs_f32x2{w[2 * o], w[2 * o + 1]}, acc[p][o]);
           }
         }
     }
+    // zero outside the map (the depthwise conv's padding): only tiles on the map's border have such pixels
+    const bool tile_inside = ty0 >= 1 && ty0 + RFS_CY - 1 <= Ho && tx0 >= 1 && tx0 + RFS_CX - 1 <= Wo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int sx = tx0 - 1 + 4 * j + p;
-      const bool in_map = srow_ok && sx >= 0 && sx < Wo;
+      const float m = (tile_inside || (srow_ok && sx >= 0 && sx < Wo)) ? 0.f : -1.f;     // max(acc, 0) | min(.., 0) below
       f32x4 a, b;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        a[o] = in_map && acc[p][o] > 0.f ? acc[p][o] : 0.f;
-        b[o] = in_map && acc[p][4 + o] > 0.f ? acc[p][4 + o] : 0.f;
+      for (int o = 0; o < 2; ++o) {
+        a[2 * o] = fmaxf(acc[p][o][0], 0.f);
+        a[2 * o + 1] = fmaxf(acc[p][o][1], 0.f);
+        b[2 * o] = fmaxf(acc[p][2 + o][0], 0.f);
+        b[2 * o + 1] = fmaxf(acc[p][2 + o][1], 0.f);
+      }
+      if (!tile_inside && m < 0.f) {
+        a = f32x4{0.f, 0.f, 0.f, 0.f};
+        b = a;
       }
       tile[ty * RFS_TPITCH + 5 * j + p] = a;
       tile[(RFS_CY + ty) * RFS_TPITCH + 5 * j + p] = b;
@@ -337,17 +360,17 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
   // 3. depthwise 3x3 (8) + ReLU, 1x1 (8 -> 16) + ReLU: thread = (row py, pixels 4g .. 4g+3)
   const int py = tid >> 4, g = tid & 15;
   const bool active = py < RFS_TY;
-  float r[4][16];
+  f32x4 r[4][4];                                  // [channel quad][pixel]
   if (active) {
     const float* dW = wt.v + 224;    // [9][8]
     const float* dB = wt.v + 296;
     const float* pW = wt.v + 304;    // [16][8]
     const float* pB = wt.v + 432;
-    float d[4][8];
+    rfs_f32x2 d[4][4];                            // [pixel][pair of channels]
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) d[p][c] = dB[c];
+      for (int c = 0; c < 4; ++c) d[p][c] = rfs_f32x2{dB[2 * c], dB[2 * c + 1]};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       f32x4 ta[6], tb[6];
@@ -358,36 +381,60 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
         tb[i] = tile[(RFS_CY + py + ky) * RFS_TPITCH + x + (x >> 2)];
       }
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* w = dW + (ky * 3 + kx) * 8;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            d[p][c] = __builtin_fmaf(ta[p + kx][c], dW[(ky * 3 + kx) * 8 + c], d[p][c]);
-            d[p][4 + c] = __builtin_fmaf(tb[p + kx][c], dW[(ky * 3 + kx) * 8 + 4 + c], d[p][4 + c]);
-          }
+        for (int p = 0; p < 4; ++p) {
+          const f32x4 a = ta[p + kx], b = tb[p + kx];
+          d[p][0] = __builtin_elementwise_fma(rfs_f32x2{a[0], a[1]}, rfs_f32x2{w[0], w[1]}, d[p][0]);
+          d[p][1] = __builtin_elementwise_fma(rfs_f32x2{a[2], a[3]}, rfs_f32x2{w[2], w[3]}, d[p][1]);
+          d[p][2] = __builtin_elementwise_fma(rfs_f32x2{b[0], b[1]}, rfs_f32x2{w[4], w[5]}, d[p][2]);
+          d[p][3] = __builtin_elementwise_fma(rfs_f32x2{b[2], b[3]}, rfs_f32x2{w[6], w[7]}, d[p][3]);
+        }
+      }
     }
+    float dr[4][8];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) d[p][c] = d[p][c] > 0.f ? d[p][c] : 0.f;
+      for (int c = 0; c < 4; ++c) {
+        dr[p][2 * c] = fmaxf(d[p][c][0], 0.f);
+        dr[p][2 * c + 1] = fmaxf(d[p][c][1], 0.f);
+      }
+#pragma nounroll
+    for (int q = 0; q < 4; ++q) {                 // output channels 4q .. 4q+3: a real loop, 32 weights per trip; pW is [c][oc] here
+      rfs_f32x2 a[4][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                 // output channels 4q .. 4q+3: 32 weights per block
-      __builtin_amdgcn_sched_barrier(0);
+      for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int oc = q * 4 + e;
+        for (int h = 0; h < 2; ++h) a[p][h] = rfs_f32x2{pB[4 * q + 2 * h], pB[4 * q + 2 * h + 1]};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p][oc] = pB[oc];
+      for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int p = 0; p < 4; ++p) {
+          const rfs_f32x2 vv = {dr[p][c], dr[p][c]};
 #pragma unroll
-          for (int p = 0; p < 4; ++p) r[p][oc] = __builtin_fmaf(d[p][c], pW[oc * 8 + c], r[p][oc]);
+          for (int h = 0; h < 2; ++h)
+            a[p][h] = __builtin_elementwise_fma(vv, rfs_f32x2{pW[c * 16 + 4 * q + 2 * h], pW[c * 16 + 4 * q + 2 * h + 1]}, a[p][h]);
+        }
+      f32x4 o4[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p][oc] = r[p][oc] > 0.f ? r[p][oc] : 0.f;
+      for (int p = 0; p < 4; ++p)
+        o4[p] = f32x4{fmaxf(a[p][0][0], 0.f), fmaxf(a[p][0][1], 0.f), fmaxf(a[p][1][0], 0.f), fmaxf(a[p][1][1], 0.f)};
+      if (q == 0) {                               // wave-uniform: keeps r[][] in registers without unrolling the loop
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[0][p] = o4[p];
+      } else if (q == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[1][p] = o4[p];
+      } else if (q == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[2][p] = o4[p];
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[3][p] = o4[p];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                                // every tile read is done: window + tile become the output staging
   // 4. staging: row py, chunk (16 bytes) c of thread g at 16 g + (c ^ g)
@@ -397,19 +444,18 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = p * 4 + q;
-        lds4[py * RFS_OPITCH + 16 * g + (c ^ g)] = f32x4{r[p][4 * q], r[p][4 * q + 1], r[p][4 * q + 2], r[p][4 * q + 3]};
+        lds4[py * RFS_OPITCH + 16 * g + (c ^ g)] = r[q][p];
       }
   }
   __syncthreads();
-  float* obase = out + (size_t)img * o_img + o_off0;
-#pragma unroll 2
-  for (int f = tid; f < RFS_TY * RFS_OROW; f += 256) {
-    const int row = f / RFS_OROW, c = f - row * RFS_OROW;
-    const int oy = ty0 + row, ox = tx0 + (c >> 2);
-    if (oy >= Ho || ox >= Wo) continue;
-    const int gg = c >> 4;
-    const f32x4 v = lds4[row * RFS_OPITCH + 16 * gg + ((c & 15) ^ gg)];
-    *(f32x4*)(obase + (size_t)oy * o_row + (size_t)ox * o_pix + (c & 3) * 4) = v;
+  if (tid < RFS_OROW && tx0 + (tid >> 2) < Wo) {          // thread = chunk of a row: constant offsets, one row per trip
+    const int gg = tid >> 4;
+    const f32x4* src = lds4 + 16 * gg + ((tid & 15) ^ gg);
+    float* dst = out + (size_t)img * o_img + o_off0 + (size_t)ty0 * o_row + (size_t)(tx0 + (tid >> 2)) * o_pix + (tid & 3) * 4;
+    const int rows = Ho - ty0 < RFS_TY ? Ho - ty0 : RFS_TY;
+#pragma unroll
+    for (int row = 0; row < RFS_TY; ++row)
+      if (row < rows) *(f32x4*)(dst + (size_t)row * o_row) = src[row * RFS_OPITCH];
   }
 }
 
@@ -427,6 +473,8 @@ int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w
   for (int o = 0; o < 8; ++o)                                           // (o, c, ky, kx) -> (ky, kx, c; o)
     for (int c = 0; c < 3; ++c)
       for (int t = 0; t < 9; ++t) wt.v[(t * 3 + c) * 8 + o] = weights_host[o * 27 + c * 9 + t];
+  for (int oc = 0; oc < 16; ++oc)                                       // (oc, c) -> (c, oc)
+    for (int c = 0; c < 8; ++c) wt.v[304 + c * 16 + oc] = weights_host[304 + oc * 8 + c];
   hipLaunchKernelGGL(rf_stem_kernel, dim3((out.w + RFS_TX - 1) / RFS_TX, (out.h + RFS_TY - 1) / RFS_TY, n), dim3(256), 0, ctx->stream,
                      frames_dev, h, w, wt, out.dev, out.h, out.w, (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c,
                      out.c, (int)out.off(0, 0, 0));
