@@ -301,10 +301,44 @@ int ta_model_run_ops(ta_model* m) {
     bool on;
     ~fin_t() { if (on) print_op_profile(m, ev); }
   } fin{m, ev, prof_ops};
+  // lanes: an op with lane L != 0 goes to side stream L - 1, which first waits for everything queued on the main stream
+  // so far (the packer places a branch right behind the op that produces its input); the main stream waits for the
+  // branches at the end of the program.  The loader checked that nothing outside a branch touches what it writes.
+  static const bool no_lanes = getenv("TA_NO_LANES") != nullptr;          // A/B switch
+  const bool lanes_on = !prof_ops && !ctx->profiling && !no_lanes;        // profiles time a serial program
+  struct lanes_t {
+    ta_ctx* ctx;
+    hipStream_t main;
+    bool started[2] = {false, false};
+    ~lanes_t() {                                                           // also on an error return
+      ctx->stream = main;
+      for (int i = 0; i < 2; ++i)
+        if (started[i]) {
+          (void)hipEventRecord(ctx->side_join[i], ctx->side_stream[i]);
+          (void)hipStreamWaitEvent(main, ctx->side_join[i], 0);
+        }
+    }
+  } lanes{ctx, ctx->stream};
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     const ta_op_desc& op = m->ops[oi];
     const ta_tensor& ti = m->tensors[op.in];
     const ta_tensor& to = m->tensors[op.out];
+    const int lane = lanes_on ? (op.variant >> 17) & 3 : 0;
+    ctx->stream = lanes.main;
+    if (lane) {
+      const int li = lane - 1;
+      if (!ctx->side_stream[li]) {
+        TA_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream[li], hipStreamNonBlocking));
+        TA_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork[li], hipEventDisableTiming));
+        TA_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[li], hipEventDisableTiming));
+      }
+      if (!lanes.started[li]) {
+        TA_HIP(ctx, hipEventRecord(ctx->side_fork[li], lanes.main));
+        TA_HIP(ctx, hipStreamWaitEvent(ctx->side_stream[li], ctx->side_fork[li], 0));
+        lanes.started[li] = true;
+      }
+      ctx->stream = ctx->side_stream[li];
+    }
     struct evp_t {
       hipEvent_t e;
       hipStream_t s;
@@ -386,6 +420,7 @@ int ta_model_run_ops(ta_model* m) {
         }
         p.k_split = m->splitk_ws ? ta_conv_ksplit(p.coutp, p.n_slabs, conv_ksplit_eligible(op, ti.fmt), (op.variant >> 8) & 255) : 1;
         p.partial = m->splitk_ws;
+        if (lane) p.k_split = 1;                       // the K-split workspace belongs to the main stream
         TA_TRY(ta_launch_conv(ctx, p, flops));
         break;
       }
@@ -474,7 +509,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 5) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 6) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -518,6 +553,33 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     if (bad) {
       delete m;
       return ta_fail(ctx, TA_E_INVALID, "model blob: malformed op");
+    }
+  }
+  {  // lanes (variant bits 17..18): a branch may read what earlier main-stream ops wrote and its own tensors; nothing outside
+     // the branch may touch what it writes, nothing later may write what it reads, and it takes plain convs only
+    std::vector<int> writer_lane(h.n_tensors, 0), reader_lanes(h.n_tensors, 0);
+    bool bad = false;
+    for (auto& op : m->ops) {
+      const int lane = (op.variant >> 17) & 3;
+      if (lane == 3 || (lane && (op.type != TA_OP_CONV || ((op.variant >> 8) & 255) > 1 || op.pool))) bad = true;
+      const int reads[3] = {op.in, op.res, -1};
+      for (int t : reads) {
+        if (t < 0) continue;
+        if (writer_lane[t] && writer_lane[t] != lane) bad = true;            // a branch's result read outside the branch
+        reader_lanes[t] |= 1 << lane;
+      }
+      const int writes[2] = {op.out, op.out2};
+      for (int t : writes) {
+        if (t < 0) continue;
+        if (reader_lanes[t] & ~(1 << lane)) bad = true;                      // written while another lane may still read it
+        if (writer_lane[t] && writer_lane[t] != lane) bad = true;
+        if (lane) writer_lane[t] = lane;
+        else if (reader_lanes[t] >> 1) bad = true;
+      }
+    }
+    if (bad) {
+      delete m;
+      return ta_fail(ctx, TA_E_INVALID, "model blob: an op lane (side stream) shares tensors with ops outside it");
     }
   }
   hipError_t e = hipMalloc((void**)&m->weights_dev, h.weights_bytes ? h.weights_bytes : 16);

@@ -156,6 +156,14 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (ctx->range_flag) (void)hipFree(ctx->range_flag);
   if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
   for (auto& e : ctx->frame_cache) (void)hipFree(e.second);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->side_stream[i]) {
+      (void)hipStreamSynchronize(ctx->side_stream[i]);
+      (void)hipStreamDestroy(ctx->side_stream[i]);
+    }
+    if (ctx->side_fork[i]) (void)hipEventDestroy(ctx->side_fork[i]);
+    if (ctx->side_join[i]) (void)hipEventDestroy(ctx->side_join[i]);
+  }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -64,7 +64,8 @@ struct ta_op_desc {
   int32_t variant;                    // bits 0..7: 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests);
                                       // bits 8..15: K-split factor fixed by the packer for this layer (0 = the library's rule);
                                       // bit 16: `scale2_off` holds a border-class bias table [16][coutp] (3x3, stride 1, pad 1, no
-                                      // second output): a per-channel affine of the INPUT is folded into the weights
+                                      // second output): a per-channel affine of the INPUT is folded into the weights;
+                                      // bits 17..18: lane -- 1 / 2 = the op runs on side stream 1 / 2 (ta_model_run_ops)
   int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
   int32_t wscale_log2;                // f16x3: the packed weights are W * 2^wscale_log2 (their lo halves stay normal half floats);
                                       // the epilogue multiplies the sums by 2^-wscale_log2 (exact).  0 in the other modes
@@ -125,6 +126,11 @@ struct ta_ctx {
     };
     std::vector<over_t> over;
   } pose_dbg;
+  // side streams of the op programs (ta_op_desc.variant bits 17..18 = lane 1..2): independent branches of a graph --
+  // RetinaFace's context modules + heads of the stride-32 / 16 levels, 4 small launches each -- run beside the main
+  // stream's ops instead of in front of them (fork / join with events, ta_model_run_ops).  Created on first use.
+  hipStream_t side_stream[2] = {nullptr, nullptr};
+  hipEvent_t side_fork[2] = {nullptr, nullptr}, side_join[2] = {nullptr, nullptr};
   // conv kernel selection (ta_debug_conv_variant, or TA_CONV_PREFER for tools): 0 = automatic, else the TA_CV_* variant
   // every conv that variant CAN run is launched on (others stay automatic);
   // conv_counts[v] = launches per variant since the last ta_debug_conv_counts(reset)

@@ -37,7 +37,7 @@ _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 5            # 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+BLOB_VERSION = 6            # 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3}
@@ -115,6 +115,7 @@ class Program:
         self.outputs = []
         self.f32_only = set()
         self.allow_split = True
+        self.lane = 0          # convs emitted while this is 1 / 2 run on that side stream (ta_op_desc.variant bits 17..18)
 
     def tensor(self, channels, halo, alias_of=-1, name=None, f32=False):
         """f32=True pins the tensor to plain float32 (outputs read by post-processing kernels / the host).
@@ -207,7 +208,7 @@ class Program:
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
-                  groups=groups, variant=variant | (int(k_split) << 8), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu),
+                  groups=groups, variant=variant | (int(k_split) << 8) | (self.lane << 17), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu),
                   scale2_off=scale2_off9 if bias9 is not None else vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
@@ -670,25 +671,15 @@ def pack_retinaface(sd, precision='f32', fused=None):
     def rcbr(p):
         return cbr(p + '.0', p + '.1', e2, bias=True)
 
-    W, b = rcbr('refiner.conv_stride32')
-    p32 = P.tensor(64, 1, name='p32')
-    P.conv(f32, p32, W, b, act=ACT_RELU, precision=rp)
-    W, b = rcbr('refiner.conv_stride16')
-    s16 = P.tensor(64, 1)
-    P.conv(f16, s16, W, b, act=ACT_RELU, res=p32, res_up2=1, precision=rp)
-    W, b = rcbr('refiner.aggr_stride16')
-    p16 = P.tensor(64, 1, name='p16')
-    P.conv(s16, p16, W, b, act=ACT_RELU, precision=rp)
-    W, b = rcbr('refiner.conv_stride8')
-    s8 = P.tensor(64, 1)
-    P.conv(f8, s8, W, b, act=ACT_RELU, res=p16, res_up2=1, precision=rp)
-    W, b = rcbr('refiner.aggr_stride8')
-    p8 = P.tensor(64, 1, name='p8')
-    P.conv(s8, p8, W, b, act=ACT_RELU, precision=rp)
-
     A = arch.RETINA_NUM_ANCHORS
     heads = {}
-    for s, x in ((32, p32), (16, p16), (8, p8)):
+    # The context module + heads of a pyramid level depend on that level's map only.  The stride-32 and stride-16 levels are
+    # 4 launches of 9-22 us each (a few dozen tiles: launch latency, not work): they go to side streams ("lanes") right
+    # behind the op that finishes their map and run beside the rest of the refiner instead of in front of it.
+    use_lanes = not os.environ.get('TERRAN_AMD_NO_DETECTOR_LANES')
+
+    def context_and_heads(s, x, lane):
+        P.lane = lane if use_lanes else 0
         p = 'refiner.context_stride%d' % s
         ctx = P.tensor(96, 1)
         W3, b3 = rcbr(p + '.context_3x3')
@@ -710,6 +701,26 @@ def pack_retinaface(sd, precision='f32', fused=None):
         hd = P.tensor(16 * A, 0, name='head%d' % s, f32=True)
         P.conv(ctx, hd, Wh, bh, ch_pos=pos, cin_p=96, precision=rp)
         heads[s] = hd
+        P.lane = 0
+
+    W, b = rcbr('refiner.conv_stride32')
+    p32 = P.tensor(64, 1, name='p32')
+    P.conv(f32, p32, W, b, act=ACT_RELU, precision=rp)
+    context_and_heads(32, p32, 1)
+    W, b = rcbr('refiner.conv_stride16')
+    s16 = P.tensor(64, 1)
+    P.conv(f16, s16, W, b, act=ACT_RELU, res=p32, res_up2=1, precision=rp)
+    W, b = rcbr('refiner.aggr_stride16')
+    p16 = P.tensor(64, 1, name='p16')
+    P.conv(s16, p16, W, b, act=ACT_RELU, precision=rp)
+    context_and_heads(16, p16, 2)
+    W, b = rcbr('refiner.conv_stride8')
+    s8 = P.tensor(64, 1)
+    P.conv(f8, s8, W, b, act=ACT_RELU, res=p16, res_up2=1, precision=rp)
+    W, b = rcbr('refiner.aggr_stride8')
+    p8 = P.tensor(64, 1, name='p8')
+    P.conv(s8, p8, W, b, act=ACT_RELU, precision=rp)
+    context_and_heads(8, p8, 0)
     P.outputs = [heads[32], heads[16], heads[8]]
     return P
 

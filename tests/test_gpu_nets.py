@@ -92,6 +92,26 @@ def test_arcface_net(ctx, states, precision):
     print('arcface', precision, 'max err', e, 'scale', np.abs(emb).max())
 
 
+@pytest.mark.parametrize('shape', [(1, 27, 123), (1, 29, 125), (2, 57, 249), (1, 5, 7), (1, 56, 248), (1, 31, 126), (3, 16, 16)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_retinaface_front_tile_edges(ctx, states, shape):
+    """rf_stem_kernel works on 14 x 62 output tiles from aligned dwords of the frame rows: maps of exactly one tile / one
+    pixel more, every row misalignment (W * 3 mod 4 = 0..3), frames smaller than a tile; the stride-8 / 16 / 32 features
+    (everything downstream of the front) against the oracle."""
+    from terran_amd import lib
+    _prec[0] = 'f32'
+    from oracle import nets
+    sd = states('retinaface')
+    m = lib.Model(ctx, pack.pack_retinaface(sd, 'f32', fused=True))
+    images = synth.frames(50 + shape[1], *shape)
+    m.forward_frames(ctx.upload(images))
+    x = torch.from_numpy(images.astype(np.float32)).permute(0, 3, 1, 2).flip(1).contiguous()
+    taps = {}
+    nets.retinaface_forward(sd, x, taps)
+    for s_ in (8, 16, 32):
+        _close(m.read('feat%d' % s_), taps['feat%d' % s_].numpy(), what='feat%d' % s_)
+
+
 @pytest.mark.parametrize('fused', [True, False], ids=['fused', 'layerwise'])
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_retinaface_net(ctx, states, precision, fused):
