@@ -9,11 +9,15 @@
 // single-rounded (this file is compiled with -ffp-contract=off) so decisions are bit-exact with
 // oracle/retinaface_post.py when fed the same numbers.
 #include <string.h>
+#include <vector>
 
 #include "ta_internal.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RF_THREADS 1024
 #define RF_LDS_KEYS 8192
+#define RF_FAST_C 1024                 // candidates up to which the NMS runs on a suppression matrix in LDS (see step 4)
+#define RF_FAST_LDS (24 * 1024 + (RF_FAST_C / 64) * (RF_FAST_C / 64 + 1) / 2 * 64 * 8)   // keys 8 KB | boxes 16 KB | matrix 68 KB
 #define RF_LDS_MAX (159 * 1024)     // dynamic LDS the kernel may be launched with (the attribute and the limit check agree)
 
 struct rf_level {
@@ -29,6 +33,7 @@ struct rf_params {
   int T;               // anchors per image
   int cls_is_prob;     // heads hold softmax probabilities (reference layout) instead of logits
   float score_thr, nms_thr;
+  float margin;        // fg - bg below this: the score is clearly under score_thr (-inf: no shortcut)
   unsigned long long* keys;   // [N][P_max] global sort buffer (used when candidates > RF_LDS_KEYS)
   int p_max;
   float* boxes;        // [N][T][4]  sorted candidates, decoded
@@ -37,6 +42,8 @@ struct rf_params {
   int* keep;           // [N][T] sorted positions kept by NMS
   int* counts;         // [N] kept
   int* ncand;          // [N] candidates
+  long long* dbg;
+  int fast_max;        // candidates up to which the NMS takes the suppression-matrix path (RF_FAST_C; tools: TA_RF_FAST_MAX)
 };
 
 __device__ __forceinline__ const float* rf_cell(const rf_level& L, int img, int t, int& a) {
@@ -57,6 +64,19 @@ __device__ __forceinline__ float rf_score(const rf_params& p, int img, int t) {
   return ef / (eb + ef);
 }
 
+// 64-bit value of lane `l` (wave-uniform l).  The builtin returns a SIGNED int: the halves go through unsigned first
+__device__ __forceinline__ unsigned long long rf_readlane64(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// first word of row i of the packed suppression matrix: rows of block b = i / 64 hold W - b words
+__device__ __forceinline__ int rf_row_off(int i, int W) {
+  const int b = i >> 6;
+  return 64 * (b * W - b * (b - 1) / 2) + (i - 64 * b) * (W - b);
+}
+
 __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* lkeys = (unsigned long long*)smem;                    // RF_LDS_KEYS
@@ -68,36 +88,96 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* gkeys = p.keys + (size_t)img * p.p_max;
 
+  if (p.dbg && tid == 0) p.dbg[img * 8 + 0] = wall_clock64();
   // ---- 1. threshold + ordered compaction into gkeys -----------------------------------------
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < p.T; t0 += RF_THREADS) {
-    const int t = t0 + tid;
-    float sc = 0.f;
-    bool pass = false;
-    if (t < p.T) {
-      sc = rf_score(p, img, t);
-      pass = sc >= p.score_thr;
+  // thread = a contiguous run of anchors: count the passing ones, one exclusive prefix sum over the workgroup (shuffles
+  // inside a wave, the 16 wave totals through LDS), then the run is scored again and its keys written in place -- the order
+  // is the anchor order, as with a ballot per 1024 anchors, for two barriers instead of four per 1024 anchors.
+  // thread = a contiguous run of CELLS (2 anchors each: one 16-byte load brings bg0 bg1 fg0 fg1), four cells at a time so
+  // that their loads are in flight together.  (level, y, x) of the first cell once, then increments -- no division per
+  // anchor.  An anchor whose logit margin fg - bg lies clearly below logit(threshold) (p.margin, 1e-2 of slack: the float
+  // softmax is good to ~1e-6) fails the exact test too and skips the two exps and the division.
+  const int ncell = p.T >> 1;
+  const int perc = (ncell + RF_THREADS - 1) / RF_THREADS;
+  const int c0 = tid * perc, c1 = (c0 + perc < ncell) ? c0 + perc : ncell;
+  const int per = 2 * perc, a0 = 2 * c0, a1 = 2 * c1;
+  int cnt = 0;
+  unsigned long long bits = 0;                       // which anchors of the run passed (runs of up to 64; longer: rescored)
+  if (c0 < c1) {
+    int l = a0 >= p.lv[2].t0 ? 2 : (a0 >= p.lv[1].t0 ? 1 : 0);
+    const int cell = (a0 - p.lv[l].t0) >> 1;
+    int y = cell / p.lv[l].fw, x = cell - y * p.lv[l].fw;
+    const float* c = p.lv[l].head + (size_t)img * p.lv[l].img + (size_t)y * p.lv[l].row + (size_t)x * p.lv[l].pix + p.lv[l].off0;
+    for (int q = c0; q < c1; q += 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = *(const f32x4*)c;                     // past the run's end: the last cell again (ignored below)
+        if (q + k + 1 < c1) {
+          c += p.lv[l].pix;
+          if (++x == p.lv[l].fw) {
+            x = 0;
+            ++y;
+            c = p.lv[l].head + (size_t)img * p.lv[l].img + (size_t)y * p.lv[l].row + p.lv[l].off0;
+          }
+          if (l < 2 && 2 * (q + k + 1) == p.lv[l + 1].t0) {
+            ++l;
+            x = y = 0;
+            c = p.lv[l].head + (size_t)img * p.lv[l].img + p.lv[l].off0;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if (q + k >= c1) continue;
+          bool pass;
+          if (p.cls_is_prob) {
+            pass = v[k][2 + a] >= p.score_thr;
+          } else {
+            const float bg = v[k][a], fg = v[k][2 + a];
+            pass = false;
+            if (!(fg - bg < p.margin)) {             // also taken by NaNs: the exact test decides
+              const float m = fmaxf(bg, fg);
+              const float eb = expf(bg - m), ef = expf(fg - m);
+              pass = ef / (eb + ef) >= p.score_thr;
+            }
+          }
+          if (pass) {
+            ++cnt;
+            const int o = 2 * (q + k - c0) + a;
+            if (o < 64) bits |= 1ull << o;
+          }
+        }
     }
-    const unsigned long long bal = __ballot(pass);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wv] = __popcll(bal);
-    __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wv; ++w) off += wave_tot[w];
-    if (pass) {
-      // ascending key order == descending score, then ascending anchor index
-      const unsigned hi = 0xFFFFFFFFu - __float_as_uint(sc);
-      gkeys[off + before] = ((unsigned long long)hi << 32) | (unsigned)t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int w = 0; w < 16; ++w) tot += wave_tot[w];
-      s_base += tot;
-    }
-    __syncthreads();
   }
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = incl - cnt;
+  for (int w = 0; w < wv; ++w) off += wave_tot[w];
+  if (tid == RF_THREADS - 1) s_base = off + cnt;
+  if (per <= 64) {
+    while (bits) {
+      const int t = a0 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      // ascending key order == descending score, then ascending anchor index
+      const unsigned hi = 0xFFFFFFFFu - __float_as_uint(rf_score(p, img, t));
+      gkeys[off++] = ((unsigned long long)hi << 32) | (unsigned)t;
+    }
+  } else {
+    for (int t = a0; t < a1; ++t) {
+      const float sc = rf_score(p, img, t);
+      if (sc >= p.score_thr) gkeys[off++] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(sc)) << 32) | (unsigned)t;
+    }
+  }
+  __syncthreads();
   const int C = s_base;
   if (tid == 0) p.ncand[img] = C;
   if (C == 0) {
@@ -105,6 +185,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
     return;
   }
 
+  if (p.dbg && tid == 0) p.dbg[img * 8 + 1] = wall_clock64();
   // ---- 2. bitonic sort of the keys (LDS when they fit) ---------------------------------------
   int P = 1;
   while (P < C) P <<= 1;
@@ -131,7 +212,13 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
     }
   }
 
+  if (p.dbg && tid == 0) p.dbg[img * 8 + 2] = wall_clock64();
   // ---- 3. decode the sorted candidates ---------------------------------------------------------
+  // C <= RF_FAST_C (the keys then occupy the first 8 KB of the key region): the decoded boxes also stay in LDS at +8 KB and
+  // the suppression matrix of step 4 goes to +24 KB -- row i holds words i / 64 .. W - 1 only (j > i), rows packed
+  const bool fast = C <= p.fast_max && keys == lkeys;
+  f32x4* sbox = (f32x4*)(smem + 8 * 1024);
+  unsigned long long* smask = (unsigned long long*)(smem + 24 * 1024);
   float* boxes = p.boxes + (size_t)img * p.T * 4;
   float* lmks = p.lmks + (size_t)img * p.T * 10;
   float* scores = p.scores + (size_t)img * p.T;
@@ -153,10 +240,9 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
     const float* bd = c + 4 + a * 4;
     const float pcx = bd[0] * w + cx, pcy = bd[1] * h + cy;
     const float pw = expf(bd[2]) * w, ph = expf(bd[3]) * h;
-    boxes[i * 4 + 0] = pcx - 0.5f * (pw - 1.0f);
-    boxes[i * 4 + 1] = pcy - 0.5f * (ph - 1.0f);
-    boxes[i * 4 + 2] = pcx + 0.5f * (pw - 1.0f);
-    boxes[i * 4 + 3] = pcy + 0.5f * (ph - 1.0f);
+    const f32x4 bx = {pcx - 0.5f * (pw - 1.0f), pcy - 0.5f * (ph - 1.0f), pcx + 0.5f * (pw - 1.0f), pcy + 0.5f * (ph - 1.0f)};
+    *(f32x4*)(boxes + i * 4) = bx;
+    if (fast) sbox[i] = bx;
     const float* ld = c + 12 + a * 10;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -167,8 +253,71 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
   for (int i = tid; i < (C + 31) / 32; i += RF_THREADS) flags[i] = 0;
   __syncthreads();
 
+  if (p.dbg && tid == 0) p.dbg[img * 8 + 3] = wall_clock64();
   // ---- 4. greedy NMS ------------------------------------------------------------------------
   int* keep = p.keep + (size_t)img * p.T;
+  if (fast) {
+    // The greedy loop below costs a barrier (and, from global memory, a box) per kept detection: ~0.7 us each, 265 us per
+    // image at 1080p (360 candidates) -- a quarter of the detector.  Up to RF_FAST_C candidates the same decisions come
+    // from a suppression MATRIX built by all 16 waves at once (wave = (i, 64 candidates j): one IoU per lane, the ballot is
+    // the row's word) and one wave's walk over it: lane w keeps word w of the removed set; candidate i is kept iff its
+    // bit is clear, and then ORs row i in.  Same IoU expression, same `>`: the kept set equals the loop's bit for bit.
+    const int W = (C + 63) >> 6;
+    for (int i = wv; i < C; i += RF_THREADS / 64) {          // wave = row i, lane = candidate j of word w
+      const f32x4 a = sbox[i];
+      const float area = (a[2] - a[0]) * (a[3] - a[1]);
+      const int ro = rf_row_off(i, W) - (i >> 6);
+      for (int w = i >> 6; w < W; ++w) {
+        const int j = w * 64 + lane;
+        bool sup = false;
+        if (j > i && j < C) {
+          const f32x4 b = sbox[j];
+          const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+          const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+          const float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
+          const float inter = iw * ih;
+          const float ovr = inter / (area + (b[2] - b[0]) * (b[3] - b[1]) - inter);
+          sup = ovr > p.nms_thr;
+        }
+        const unsigned long long m = __ballot(sup);
+        if (lane == 0) smask[ro + w] = m;
+      }
+    }
+    __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[img * 8 + 4] = wall_clock64();
+    if (wv == 0) {
+      // one wave walks the matrix a block of 64 candidates at a time.  Lane l holds word l of the removed set.  Inside
+      // block w only the block's own column of the rows matters: lane i holds that word of row 64 w + i, the 64 decisions
+      // run on scalars (readlane), and the kept rows' later words are then ORed in with one wave-wide reduction per word.
+      unsigned long long removed = 0;
+      int kept = 0;
+      for (int w = 0; w < W; ++w) {
+        const int i0 = w * 64, n = (C - i0 < 64) ? C - i0 : 64;
+        const int row = i0 + lane;
+        const int ro = (lane < n) ? rf_row_off(row, W) : 0;   // row's word w is its first
+        const unsigned long long own = (lane < n) ? smask[ro] : 0ull;
+        unsigned long long cur = rf_readlane64(removed, w);
+        unsigned long long keptbits = 0;
+        for (int i = 0; i < n; ++i) {
+          if ((cur >> i) & 1ull) continue;
+          keptbits |= 1ull << i;
+          cur |= rf_readlane64(own, i);
+        }
+        const bool mine = (keptbits >> lane) & 1ull;
+        if (mine) keep[kept + __popcll(keptbits & ((1ull << lane) - 1ull))] = row;
+        kept += __popcll(keptbits);
+        for (int w2 = w + 1; w2 < W; ++w2) {                  // OR of the kept rows' word w2 over the wave -> lane w2
+          unsigned long long v = mine ? smask[ro + w2 - w] : 0ull;
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+          if (lane == w2) removed |= v;
+        }
+      }
+      if (lane == 0) p.counts[img] = kept;
+      if (p.dbg && lane == 0) { p.dbg[img * 8 + 5] = wall_clock64(); p.dbg[img * 8 + 6] = C; p.dbg[img * 8 + 7] = kept; }
+    }
+    return;
+  }
   int kept = 0;
   for (int i = 0; i < C; ++i) {
     if ((flags[i >> 5] >> (i & 31)) & 1u) continue;   // uniform: stable since the last barrier
@@ -189,6 +338,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_select_kernel(const rf_params p
     __syncthreads();
   }
   if (tid == 0) p.counts[img] = kept;
+  if (p.dbg && tid == 0) { p.dbg[img * 8 + 4] = p.dbg[img * 8 + 3]; p.dbg[img * 8 + 5] = wall_clock64(); p.dbg[img * 8 + 6] = C; p.dbg[img * 8 + 7] = kept; }
 }
 
 // gather kept detections of all images into packed output arrays (image order preserved)
@@ -259,6 +409,11 @@ static int rf_postprocess_dev(ta_ctx* ctx, const ta_tensor heads[3], int N, int 
   p.T = T;
   p.cls_is_prob = cls_is_prob;
   p.score_thr = score_thr;
+  p.margin = -INFINITY;
+  if (score_thr > 1e-4f && score_thr < 1.0f - 1e-4f) {
+    const double lg = log((double)score_thr / (1.0 - (double)score_thr));
+    p.margin = (float)(lg - 0.01 - 0.001 * fabs(lg));
+  }
   p.nms_thr = nms_thr;
   int pmax = 1;
   while (pmax < T) pmax <<= 1;
@@ -284,8 +439,14 @@ static int rf_postprocess_dev(ta_ctx* ctx, const ta_tensor heads[3], int N, int 
   p.keep = (int*)(scr + o_keep);
   p.counts = (int*)(scr + o_counts);
   p.ncand = (int*)(scr + o_ncand);
-  const size_t lds = (size_t)RF_LDS_KEYS * 8 + (size_t)(((T + 31) / 32 + 3) / 4 * 4) * 4 + 32 * 4;
+  size_t lds = (size_t)RF_LDS_KEYS * 8 + (size_t)(((T + 31) / 32 + 3) / 4 * 4) * 4 + 32 * 4;
+  if (lds < RF_FAST_LDS) lds = RF_FAST_LDS;              // the suppression-matrix path reuses the key / bitmap space and then some
   if (lds > RF_LDS_MAX) return ta_fail(ctx, TA_E_OVERFLOW, "retinaface: %d anchors per image exceed the NMS bitmap limit", T);
+  static long long* dbg_dev = nullptr;
+  if (getenv("TA_RF_DEBUG") && !dbg_dev) (void)hipMalloc((void**)&dbg_dev, 8 * 8 * 4096);
+  p.dbg = dbg_dev;
+  static const int fast_max = getenv("TA_RF_FAST_MAX") ? atoi(getenv("TA_RF_FAST_MAX")) : RF_FAST_C;
+  p.fast_max = fast_max < RF_FAST_C ? fast_max : RF_FAST_C;
   {
     ta_prof_scope scope(ctx, 3, (double)N * T * 32 * 4);
     TA_SET_LDS_ATTR(ctx, rf_select_kernel, RF_LDS_MAX);
@@ -294,6 +455,11 @@ static int rf_postprocess_dev(ta_ctx* ctx, const ta_tensor heads[3], int N, int 
   }
   TA_HIP(ctx, hipMemcpyAsync(counts, p.counts, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (dbg_dev) {
+    std::vector<long long> h(8 * N);
+    (void)hipMemcpy(h.data(), dbg_dev, 8 * 8 * N, hipMemcpyDeviceToHost);
+    for (int i = 0; i < N; ++i) fprintf(stderr, "rf img %d C %lld kept %lld: compact %.1f sort %.1f decode %.1f matrix %.1f scan %.1f us\n", i, h[8*i+6], h[8*i+7], (h[8*i+1]-h[8*i])/100.0, (h[8*i+2]-h[8*i+1])/100.0, (h[8*i+3]-h[8*i+2])/100.0, (h[8*i+4]-h[8*i+3])/100.0, (h[8*i+5]-h[8*i+4])/100.0);
+  }
   long long total = 0;
   for (int i = 0; i < N; ++i) total += counts[i];
   if (required) *required = (int32_t)total;
