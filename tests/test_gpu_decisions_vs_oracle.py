@@ -193,3 +193,27 @@ def test_arcface_embeddings_vs_oracle(states):
         print('arcface 64 crops, device %s vs oracle: %s' % (mode, table[mode]))
     assert table['f32']['max_abs'] < 5e-6
     assert table[HEADLINE]['max_abs'] <= max(2 * table['f32']['max_abs'], 2e-6)
+
+
+@pytest.mark.parametrize('threshold', [0.02, 0.3, 0.45, 0.55, 0.6, 0.9, 0.0, 1.0])
+def test_retinaface_score_thresholds_vs_oracle(states, threshold):
+    """rf_select_kernel skips the softmax of an anchor whose logit margin lies clearly below logit(threshold) (1e-2 of slack)
+    and scores the rest exactly: at thresholds far from 0.5 -- where the margin test works on large logit differences --
+    and at the ends (0 and 1: no shortcut; everything / nothing passes) the kept sets must still be the oracle's."""
+    from oracle import pipeline
+    from terran_amd import RetinaFace
+    sd = states('retinaface')
+    model = RetinaFace(device=0, state=sd, precision='f32')
+    dets = ddets = 0
+    for k in range(2):
+        frames = synth.frames(7000 + k, 4, 208, 277)
+        ref = pipeline.retinaface_call(sd, frames, threshold=threshold)
+        got = model.call(frames, threshold=threshold)
+        for g, r in zip(got, ref):
+            g, r = _det_keys(g), _det_keys(r)
+            dets += len(r)
+            ddets += len(set(g) ^ set(r))
+    print('threshold %g: %d detections, %d differ' % (threshold, dets, ddets))
+    if threshold <= 0.55:                      # the seeded random detector scores 0.35 .. 0.65
+        assert dets > 100
+    assert ddets <= max(2, dets // 500), (threshold, dets, ddets)

@@ -92,6 +92,46 @@ def test_arcface_net(ctx, states, precision):
     print('arcface', precision, 'max err', e, 'scale', np.abs(emb).max())
 
 
+def test_retinaface_lanes_equal_the_serial_program(ctx, states, monkeypatch):
+    """The context modules + heads of the stride-32 / 16 levels run on side streams (op lanes): every head must come out
+    bit-identical to the program that keeps them in order on the main stream, call after call (fork / join per forward)."""
+    from terran_amd import lib
+    sd = states('retinaface')
+    images = synth.frames(61, 3, 150, 203)
+    fr = ctx.upload(images)
+    lanes = lib.Model(ctx, pack.pack_retinaface(sd, 'f16x3'))
+    monkeypatch.setenv('TERRAN_AMD_NO_DETECTOR_LANES', '1')
+    serial = lib.Model(ctx, pack.pack_retinaface(sd, 'f16x3'))
+    assert {(op['variant'] >> 17) & 3 for op in pack.pack_retinaface(sd, 'f16x3').ops} == {0}
+    monkeypatch.delenv('TERRAN_AMD_NO_DETECTOR_LANES')
+    assert {(op['variant'] >> 17) & 3 for op in pack.pack_retinaface(sd, 'f16x3').ops} == {0, 1, 2}
+    serial.forward_frames(fr)
+    want = {k: serial.read(k) for k in ('head32', 'head16', 'head8', 'ctx32_7x7', 'ctx16_3x3')}
+    for _ in range(3):
+        lanes.forward_frames(fr)
+        for k, v in want.items():
+            assert np.array_equal(lanes.read(k), v), k
+
+
+def test_lane_sharing_a_tensor_with_the_main_stream_is_refused(ctx):
+    """The loader checks what makes lanes safe: an op outside a lane may not read what the lane writes."""
+    from terran_amd import lib
+    rng = np.random.default_rng(5)
+    P = pack.Program(pack.MODEL_OPENPOSE, 'f32')
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    t1, t2, t3 = P.tensor(32, 1), P.tensor(32, 1), P.tensor(32, 0)
+    w = lambda co, ci, k: rng.normal(0, 0.1, (co, ci, k, k)).astype(np.float32)
+    P.conv(t0, t1, w(32, 3, 3), np.zeros(32, np.float32))
+    P.lane = 1
+    P.conv(t1, t2, w(32, 32, 3), np.zeros(32, np.float32))
+    P.lane = 0
+    P.conv(t2, t3, w(32, 32, 1), np.zeros(32, np.float32))          # reads the lane's output on the main stream
+    P.outputs = [t3]
+    with pytest.raises(lib.TerranAmdError):
+        lib.Model(ctx, P)
+
+
 @pytest.mark.parametrize('shape', [(1, 27, 123), (1, 29, 125), (2, 57, 249), (1, 5, 7), (1, 56, 248), (1, 31, 126), (3, 16, 16)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_retinaface_front_tile_edges(ctx, states, shape):
