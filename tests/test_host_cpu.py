@@ -348,3 +348,36 @@ def test_c_result_builder_yields_the_comprehensions_objects():
             results.detections(counts.astype(np.int64), boxes, lmks, scores)
         with pytest.raises(ValueError):
             results.detections(np.array([T + 3], np.int32), boxes, lmks, scores)
+
+
+def test_detector_lanes_are_closed_branches(monkeypatch):
+    """pack.pack_retinaface marks the context module + heads of the stride-32 / 16 levels as lanes 1 / 2 (side streams,
+    ta_op_desc.variant bits 17..18).  What net.hip's loader enforces is checked here on the packed program too: a lane's ops
+    follow the op that finishes their input, write tensors nobody outside the lane touches, and read nothing that a later
+    op outside the lane writes; TERRAN_AMD_NO_DETECTOR_LANES packs the same ops without lanes."""
+    from terran_amd import pack, weights
+    sd = weights.make_retinaface_state()
+    P = pack.pack_retinaface(sd, 'f16x3')
+    lanes = [(op['variant'] >> 17) & 3 for op in P.ops]
+    assert set(lanes) == {0, 1, 2} and lanes.count(1) == 4 and lanes.count(2) == 4
+    written_by = {}
+    for i, op in enumerate(P.ops):
+        for t in (op['out'], op.get('out2', -1)):
+            if t >= 0:
+                written_by.setdefault(t, set()).add(lanes[i])
+    for i, op in enumerate(P.ops):
+        L = lanes[i]
+        for t in (op['in'], op.get('res', -1)):
+            if t < 0 or t not in written_by:
+                continue
+            assert written_by[t] <= {0, L}, (i, t)                 # reads its own lane's tensors or the main stream's
+            if L and 0 in written_by[t]:                           # ... and those were finished BEFORE the lane's first op
+                first = lanes.index(L)
+                assert all(j < first for j, o in enumerate(P.ops) if o['out'] == t and lanes[j] == 0), (i, t)
+    for L in (1, 2):                                               # a lane's ops are consecutive
+        idx = [i for i, x in enumerate(lanes) if x == L]
+        assert idx == list(range(idx[0], idx[0] + 4))
+    monkeypatch.setenv('TERRAN_AMD_NO_DETECTOR_LANES', '1')
+    Q = pack.pack_retinaface(sd, 'f16x3')
+    assert {(op['variant'] >> 17) & 3 for op in Q.ops} == {0} and len(Q.ops) == len(P.ops)
+    assert sorted(op['macs_per_pixel'] for op in Q.ops) == sorted(op['macs_per_pixel'] for op in P.ops)
