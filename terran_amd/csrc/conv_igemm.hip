@@ -53,6 +53,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //                 v_mfma_f32_32x32x16_bf16, f32 accumulate: ~1e-5 relative per product,
 //                 i.e. float32-class accuracy at 3/16 of the f32 MFMA cost.              833 TF-equivalent peak
 //   PREC_BF16   : hi*hi only (throughput mode, NOT within the 1e-3 parity bar).          2.5 PF peak
+//   PREC_F16    : hi*hi only on IEEE half words (11 bits per operand, 2^-11 per product): for networks that take no discrete
+//                 decision and whose outputs have a tolerance -- ArcFace: 3e-4 on unit-norm embedding components against a
+//                 1e-3 bar (tests/probe_embed_precision.py); same weight scaling and range flag as PREC_F16X3.
 //   PREC_F16X3  : the same three-product scheme with IEEE half words on v_mfma_f32_32x32x16_f16: x = hi + lo carries
 //                 22 significant bits, every product hi*hi / hi*lo / lo*hi is exact in the float32 accumulator and the
 //                 dropped lo*lo term is <= 2^-22 of the product -- below the rounding noise of a float32 dot product.
@@ -62,13 +65,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Weights are split at pack time ([hi x32 | lo x32] 16-bit words per 128-byte row).  Activations either arrive in the
 // same image (TA_FMT_SPLIT / TA_FMT_SPLIT16, written by the producer's epilogue) or are float32 and split in registers
 // right after the ds_read.
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16X3 = 3 };
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16X3 = 3, PREC_F16 = 4 };
 __host__ __device__ constexpr bool prec_x3(int prec) { return prec == PREC_BF16X3 || prec == PREC_F16X3; }
+__host__ __device__ constexpr bool prec_half(int prec) { return prec == PREC_F16X3 || prec == PREC_F16; }   // IEEE half words (else bf16)
 
 // one 32x32x16 MFMA on 16-bit operand fragments held as raw bits (bf16x8 is the container type for both formats)
 template <int PREC>
 __device__ __forceinline__ f32x16 ta_mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-  if constexpr (PREC == PREC_F16X3)
+  if constexpr (prec_half(PREC))
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -76,12 +80,12 @@ __device__ __forceinline__ f32x16 ta_mfma16(const bf16x8& a, const bf16x8& b, co
 // float32 -> the mode's 16-bit word (round to nearest even) and back, for operands split in registers
 template <int PREC>
 __device__ __forceinline__ __bf16 ta_to16(float x) {
-  if constexpr (PREC == PREC_F16X3) return __builtin_bit_cast(__bf16, (_Float16)x);
+  if constexpr (prec_half(PREC)) return __builtin_bit_cast(__bf16, (_Float16)x);
   else return (__bf16)x;
 }
 template <int PREC>
 __device__ __forceinline__ float ta_from16(__bf16 h) {
-  if constexpr (PREC == PREC_F16X3) return (float)__builtin_bit_cast(_Float16, h);
+  if constexpr (prec_half(PREC)) return (float)__builtin_bit_cast(_Float16, h);
   else return (float)h;
 }
 
@@ -217,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
           const int co = co_base + a * 32 + 8 * j;
           if (co < p.cout) {
             ta_st4(o, p.out_ch + co, p.out_fmt, v[a][j]);
-            if (p.prec == PREC_F16X3)
+            if (prec_half(p.prec))
               amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[a][j][0]), fabsf(v[a][j][1]))), fmaxf(fabsf(v[a][j][2]), fabsf(v[a][j][3])));
           }
         }
@@ -243,7 +247,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
             for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
             if (co < p.cout) {
               ta_st4(o2, p.o2_ch + co, p.o2_fmt, z);
-              if (p.prec == PREC_F16X3) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
+              if (prec_half(p.prec)) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
             }
           }
       }
@@ -1041,7 +1045,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   const int co = ct0 + 8 * k8;
   const float us = p.w_unscale;
   float amax = 0.f;                                // f16x3: largest |x| stored (every output of that mode, see conv_epilogue)
-  const bool chk = p.prec == PREC_F16X3, chk2 = chk && p.out2;
+  const bool chk = prec_half(p.prec), chk2 = chk && p.out2;
   if (p.k_split > 1) {                             // K-split: raw sums of this K range -> partial[ks][pixel][coutp]
     float* dst = p.partial + (size_t)ks * p.M * p.coutp + co;
     for (int row = r0; row < BM && pt0 + row < p.M; row += RPI) {
@@ -1483,7 +1487,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
       bool done = false;
-      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), PREC == PREC_F16X3>(p, lds, ct0, pt0, tid, HoWo);
+      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), prec_half(PREC)>(p, lds, ct0, pt0, tid, HoWo);
       if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
@@ -1560,7 +1564,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bh[b], acc[a][b]);
   };
-  constexpr int NREAD = PREC == PREC_BF16 ? 4 : 8;                               // ds_read_b128 per k-step
+  constexpr int NREAD = (PREC == PREC_BF16 || PREC == PREC_F16) ? 4 : 8;                               // ds_read_b128 per k-step
   constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : 4);         // MFMAs per k-step
   // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
   // use to save registers and exposes the LDS latency in front of every group of MFMAs
@@ -1609,7 +1613,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(7);                     // consumer: past E1
     bool done = false;
-    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), PREC == PREC_F16X3>(p, lds, ct0, pt0, tid, HoWo);
+    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), prec_half(PREC)>(p, lds, ct0, pt0, tid, HoWo);
     if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
@@ -1662,7 +1666,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
       ta_st4(p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0, p.o2_ch + co, p.o2_fmt, z);
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
     }
-    if (p.prec == PREC_F16X3 && !(amax <= TA_F16_MAX)) *p.range_flag = 1;
+    if (prec_half(p.prec) && !(amax <= TA_F16_MAX)) *p.range_flag = 1;
   }
 }
 
@@ -1687,7 +1691,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;      // tools: A/B
     const long long n_img = p.Ho * p.Wo > 0 ? ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo) : 0;
     auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
-    constexpr int SPLIT_FMT = PREC == PREC_F16X3 ? TA_FMT_SPLIT16 : TA_FMT_SPLIT;
+    constexpr int SPLIT_FMT = prec_half(PREC) ? TA_FMT_SPLIT16 : TA_FMT_SPLIT;
     bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == SPLIT_FMT &&
               (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
     if (p.res) ok = ok && p.res_fmt == SPLIT_FMT && fits(p.res_img, p.res_off0);
@@ -1861,7 +1865,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   p.probe = ctx->conv_probe;
   if (p.k_split < 1 || !p.partial || no_ksplit) p.k_split = 1;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
-  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16 && p.prec != PREC_F16X3)
+  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16 && p.prec != PREC_F16X3 && p.prec != PREC_F16)
     return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
   if (p.in_fmt != TA_FMT_F32 && p.in_fmt != ta_split_fmt_of(p.prec))
     return ta_fail(ctx, TA_E_INVALID, "conv: input tensor format %d does not belong to precision mode %d", p.in_fmt, p.prec);
@@ -1893,6 +1897,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
     case PREC_F32: return launch_variant<PREC_F32>(ctx, v, p);
     case PREC_BF16X3: return launch_variant<PREC_BF16X3>(ctx, v, p);
     case PREC_F16X3: return launch_variant<PREC_F16X3>(ctx, v, p);
+    case PREC_F16: return launch_variant<PREC_F16>(ctx, v, p);
     default: return launch_variant<PREC_BF16>(ctx, v, p);
   }
 }

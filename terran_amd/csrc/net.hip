@@ -532,7 +532,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
     if (op.type == TA_OP_CONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
-            op.stride <= 0 || op.wscale_log2 < -60 || op.wscale_log2 > 60 || (op.prec != 3 && op.wscale_log2 != 0) || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            op.stride <= 0 || op.wscale_log2 < -60 || op.wscale_log2 > 60 || (op.prec != 3 && op.prec != 4 && op.wscale_log2 != 0) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||

@@ -59,7 +59,7 @@ struct ta_op_desc {
   int32_t res, res_ch_off, res_up2;   // residual tensor (-1 none); res_up2: read residual at (y/2, x/2)
   int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
-  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits)
+  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits), 4 = f16 (11 bits: tolerance mode)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
   int32_t variant;                    // bits 0..7: 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests);
                                       // bits 8..15: K-split factor fixed by the packer for this layer (0 = the library's rule);
@@ -278,7 +278,7 @@ struct ta_conv_launch {
 };
 
 // the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
-static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : (prec == 3 ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */); }
+static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : ((prec == 3 || prec == 4) ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */); }
 
 // K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
 // 128 x 128 at the batch sizes in use): K is cut in a FIXED number of ranges that depends on the layer only, never on

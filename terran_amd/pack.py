@@ -40,8 +40,8 @@ assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
 BLOB_VERSION = 6            # 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
-PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3}
-SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16}     # pre-split activation format per arithmetic mode
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3, 'f16': 4}
+SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16, 4: FMT_SPLIT16}     # pre-split activation format per arithmetic mode
 
 
 def _rup(x, m):
@@ -189,7 +189,7 @@ class Program:
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
         wscale = 0
         prec = self.prec if precision is None else PRECISIONS[precision]      # a single op may run in another arithmetic mode
-        if prec == 3:
+        if prec in (3, 4):
             packed, wscale = split_f16_rows(packed)
         elif prec != 0:
             packed = split_bf16_rows(np.ascontiguousarray(packed))
@@ -396,6 +396,8 @@ OP_FEAT, OP_PAF, OP_HM, OP_XCH = 0, 128, 168, 192
 def pack_openpose(sd, precision='f32'):
     """openpose/model.py:27-141.  Stage inputs cat[PAF, HM, feat] live in two ping-pong
     192-channel tensors; every stage-output conv writes its slice directly."""
+    if precision == 'f16':            # the single-half mode is for networks without discrete decisions: pose keeps 22 bits
+        precision = 'f16x3'
     P = Program(MODEL_OPENPOSE, precision)
     t = P.tensor(4, 1, name='input')
     P.input_tensor = t
@@ -598,6 +600,8 @@ def pack_retinaface(sd, precision='f32', fused=None):
     # order of near-tied scores in 3 % of the images.  The graph is HBM-bound (35 FLOP/B), so the exact-f32 MFMA costs
     # next to nothing here: in the `bf16x3` mode the detector runs on it, and its results ARE the `f32` mode's, bit for
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
+    if precision == 'f16':            # the single-half mode is for networks without discrete decisions: the detector keeps 22 bits
+        precision = 'f16x3'
     det_prec = 'f32' if precision in ('bf16x3', 'f16x3') else precision
     P = Program(MODEL_RETINAFACE, det_prec)
     # f16x3: the REFINER (FPN laterals, 3x3 aggregations, context modules, heads: 18 dense convs, 0.75 of the detector's

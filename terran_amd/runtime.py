@@ -69,7 +69,7 @@ def resolve_precision(precision=None):
     or 'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f16x3' (the detector is
     exact f32 in every parity mode; ArcFace / OpenPose fall back to an exact-f32 twin on TA_E_RANGE, RangeFallback below)."""
     p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f16x3')
-    if p not in ('f32', 'f16x3', 'bf16x3', 'bf16'):
+    if p not in ('f32', 'f16x3', 'bf16x3', 'bf16', 'f16'):
         raise ValueError('unknown precision %r' % (p,))
     return p
 
