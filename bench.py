@@ -57,6 +57,7 @@ PEAKS = {
     'f16x3': (2500.0, 'v_mfma_f32_32x32x16_f16 x3 (hi*hi + hi*lo + lo*hi on split-half operands, f32 accumulate)', 3),
     'bf16x3': (2500.0, 'v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi, f32 accumulate)', 3),
     'bf16': (2500.0, 'v_mfma_f32_32x32x16_bf16', 1),
+    'f16': (2500.0, 'v_mfma_f32_32x32x16_f16: x3 (split-half operands) in the detector and the pose network, x1 in the embedder', 3),
 }
 HBM_PEAK_GBPS = 8000.0
 DTYPES = {'f32': 'f32',
@@ -67,7 +68,10 @@ DTYPES = {'f32': 'f32',
           'bf16x3': 'bf16x3 (ArcFace / OpenPose operands x = hi + lo as two bf16, ~16 mantissa bits; 3 bf16 MFMAs per '
                     'product term, f32 accumulate; the detector RetinaFace runs on the exact-f32 MFMA) -- passes the '
                     'same 1e-3 / bit-exact parity suite as f32',
-          'bf16': 'bf16 (f32 accumulate)'}
+          'bf16': 'bf16 (f32 accumulate)',
+          'f16': 'f16x3 for the detector and the pose network (every discrete decision at float32 grade, as in the f16x3 mode); the '
+                 'embedder ArcFace -- no decisions, north_star bar 1e-3 on the unit-norm embedding -- with ONE f16 MFMA per product '
+                 'on 2-byte half-float activations: 3.6e-4 worst embedding component vs the oracle (tolerance mode for that one task)'}
 KLASSES = ('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')
 
 
@@ -138,7 +142,7 @@ def main():
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
     ap.add_argument('--cpu-frames', type=int, default=16, help='frames in the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3', 'bf16x3', 'bf16'],
+    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3', 'bf16x3', 'bf16', 'f16'],
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or f16x3)')
     ap.add_argument('--single-mode', action='store_true',
                     help='headline measurement only (no f32 / faces-per-frame / sustained / ingest / per-model legs)')
@@ -555,7 +559,7 @@ def run(args):
     elapsed, out, klass = head['elapsed'], head['out'], head['klass']
     others = {}
     if not args.single_mode:
-        for prec in ('f32', 'bf16x3'):
+        for prec in ('f32', 'bf16x3', 'f16'):
             if prec != primary:
                 steps2 = max(L, args.steps // 2)
                 r2 = run_mode(prec, steps2)

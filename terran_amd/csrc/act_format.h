@@ -8,10 +8,14 @@
 //                    for |x| in [2^-3, 65504] (lo goes subnormal below that: the absolute error stays <= 2^-25).
 //                    |x| > 65504 does not fit: the conv epilogues that write this format raise the context's range
 //                    flag (ta_conv_launch::range_flag) and the call fails with TA_E_RANGE instead of returning numbers.
+//   TA_FMT_F16     : NHWC IEEE half, 2 bytes per element (the single-half arithmetic mode PREC_F16: operands carry 11 bits
+//                    anyway, so there is no `lo` to keep).  A pixel is c halfs = c / 2 float slots: every stride the kernels
+//                    take in floats is HALF the float32 tensor's, a 64-channel block is the 128 bytes a K slab row holds.
+//                    Same range rule as TA_FMT_SPLIT16.  c % 64 == 0.
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { TA_FMT_F32 = 0, TA_FMT_SPLIT = 1, TA_FMT_SPLIT16 = 2 };
+enum { TA_FMT_F32 = 0, TA_FMT_SPLIT = 1, TA_FMT_SPLIT16 = 2, TA_FMT_F16 = 3 };
 #define TA_F16_MAX 65504.0f
 
 typedef float ta_f32x4 __attribute__((ext_vector_type(4)));
@@ -50,12 +54,26 @@ __device__ __forceinline__ void ta_pack2(float x0, float x1, unsigned& hw, unsig
   }
 }
 
+// (x0, x1) -> two packed half floats (round to nearest even)
+__device__ __forceinline__ unsigned ta_pack_half2(float x0, float x1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, f16x2));
+}
+
 // byte offset of channel `ch`'s hi word inside a pixel of a split-format tensor (the lo word sits 64 B further)
 __device__ __forceinline__ unsigned ta_split_chan(int ch) { return (unsigned)(((ch >> 5) << 7) + ((ch & 31) << 1)); }
 
 // 4 consecutive channels ch..ch+3 (ch % 4 == 0) of the pixel whose channel-0 address is `pix`
 __device__ __forceinline__ ta_f32x4 ta_ld4(const float* pix, int ch, int fmt) {
   if (fmt == TA_FMT_F32) return *(const ta_f32x4*)(pix + ch);
+  if (fmt == TA_FMT_F16) {
+    const uint2 w = *(const uint2*)((const char*)pix + 2 * ch);
+    float v[4];
+    ta_unpack2<true>(w.x, v[0], v[1]);
+    ta_unpack2<true>(w.y, v[2], v[3]);
+    return ta_f32x4{v[0], v[1], v[2], v[3]};
+  }
   const char* b = (const char*)pix + ta_split_chan(ch);
   const uint2 h = *(const uint2*)b, l = *(const uint2*)(b + 64);
   float hv[4], lv[4];
@@ -78,6 +96,10 @@ __device__ __forceinline__ void ta_st4(float* pix, int ch, int fmt, ta_f32x4 v) 
     *(ta_f32x4*)(pix + ch) = v;
     return;
   }
+  if (fmt == TA_FMT_F16) {
+    *(uint2*)((char*)pix + 2 * ch) = make_uint2(ta_pack_half2(v[0], v[1]), ta_pack_half2(v[2], v[3]));
+    return;
+  }
   unsigned h0, h1, l0, l1;
   if (fmt == TA_FMT_SPLIT16) {
     ta_pack2<true>(v[0], v[1], h0, l0);
@@ -93,6 +115,7 @@ __device__ __forceinline__ void ta_st4(float* pix, int ch, int fmt, ta_f32x4 v) 
 
 __device__ __forceinline__ float ta_ld1(const float* pix, int ch, int fmt) {
   if (fmt == TA_FMT_F32) return pix[ch];
+  if (fmt == TA_FMT_F16) return ta_f16_val(*(const unsigned short*)((const char*)pix + 2 * ch));
   const char* b = (const char*)pix + ta_split_chan(ch);
   const unsigned h = *(const unsigned short*)b, l = *(const unsigned short*)(b + 64);
   if (fmt == TA_FMT_SPLIT16) return ta_f16_val(h) + ta_f16_val(l);

@@ -966,6 +966,17 @@ __device__ __forceinline__ ta_f32x8 ta_ld8(const float* pix, int ch, int fmt) { 
     r.b = *(const f32x4*)(pix + ch + 4);
     return r;
   }
+  if (fmt == TA_FMT_F16) {
+    const uint4 w = *(const uint4*)((const char*)pix + 2 * ch);
+    float v[8];
+    ta_unpack2<true>(w.x, v[0], v[1]);
+    ta_unpack2<true>(w.y, v[2], v[3]);
+    ta_unpack2<true>(w.z, v[4], v[5]);
+    ta_unpack2<true>(w.w, v[6], v[7]);
+    r.a = f32x4{v[0], v[1], v[2], v[3]};
+    r.b = f32x4{v[4], v[5], v[6], v[7]};
+    return r;
+  }
   const char* q = (const char*)pix + ta_split_chan(ch);
   const uint4 h = *(const uint4*)q, l = *(const uint4*)(q + 64);
   const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
@@ -991,6 +1002,11 @@ __device__ __forceinline__ void ta_st8(float* pix, int ch, int fmt, const ta_f32
   if (fmt == TA_FMT_F32) {
     *(f32x4*)(pix + ch) = v.a;
     *(f32x4*)(pix + ch + 4) = v.b;
+    return;
+  }
+  if (fmt == TA_FMT_F16) {
+    *(uint4*)((char*)pix + 2 * ch) = make_uint4(ta_pack_half2(v.a[0], v.a[1]), ta_pack_half2(v.a[2], v.a[3]),
+                                                 ta_pack_half2(v.b[0], v.b[1]), ta_pack_half2(v.b[2], v.b[3]));
     return;
   }
   const float x[8] = {v.a[0], v.a[1], v.a[2], v.a[3], v.b[0], v.b[1], v.b[2], v.b[3]};
@@ -1528,12 +1544,12 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-      if constexpr (prec_x3(PREC)) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      if constexpr (prec_x3(PREC) || PREC == PREC_F16) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       f.bh[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-      if constexpr (prec_x3(PREC)) f.bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      if constexpr (prec_x3(PREC) || PREC == PREC_F16) f.bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
     }
   };
   auto mma = [&](const Frag& f) {
@@ -1559,13 +1575,19 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bl[b], acc[a][b]);
     }
+    if constexpr (PREC == PREC_F16) {                 // a row is 64 channels of plain halfs: its second 64 bytes are 32 more of K
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.al[a], f.bl[b], acc[a][b]);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bh[b], acc[a][b]);
   };
-  constexpr int NREAD = (PREC == PREC_BF16 || PREC == PREC_F16) ? 4 : 8;                               // ds_read_b128 per k-step
-  constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : 4);         // MFMAs per k-step
+  constexpr int NREAD = PREC == PREC_BF16 ? 4 : 8;                               // ds_read_b128 per k-step
+  constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : (PREC == PREC_F16 ? 8 : 4));         // MFMAs per k-step
   // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
   // use to save registers and exposes the LDS latency in front of every group of MFMAs
   auto pin = [&]() {
@@ -1691,7 +1713,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;      // tools: A/B
     const long long n_img = p.Ho * p.Wo > 0 ? ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo) : 0;
     auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
-    constexpr int SPLIT_FMT = prec_half(PREC) ? TA_FMT_SPLIT16 : TA_FMT_SPLIT;
+    constexpr int SPLIT_FMT = PREC == PREC_F16 ? -1 : (prec_half(PREC) ? TA_FMT_SPLIT16 : TA_FMT_SPLIT);   // -1: TA_FMT_F16 tensors take the generic drain
     bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == SPLIT_FMT &&
               (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
     if (p.res) ok = ok && p.res_fmt == SPLIT_FMT && fits(p.res_img, p.res_off0);
@@ -1802,10 +1824,10 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
 // Which variants can run this conv at all (a forced variant that cannot is an error, never a silent substitution).
 static bool variant_eligible(int v, const ta_conv_launch& p) {
   const bool split_in = p.in_fmt == ta_split_fmt_of(p.prec);   // what the split-role kernel reads: float32 in f32 mode, else the mode's pre-split format
-  const bool deep = p.uniform_k && p.n_slabs >= 2;
+  const bool deep = p.uniform_k && (p.n_slabs >= 2 || p.prec == PREC_F16);   // f16 mode: a 1x1 conv over 64 channels is ONE slab of 64
   switch (v) {
     case TA_CV_GENERIC: return p.in_fmt == TA_FMT_F32 && !p.group_cout;
-    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || split_in);
+    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || (split_in && p.prec != PREC_F16));
     case TA_CV_PIPE128: return deep && p.coutp % 128 == 0 && !p.group_cout && p.in_fmt == TA_FMT_F32;
     case TA_CV_SPLIT_2x2:
     case TA_CV_SPLIT_2x2_P8:
@@ -1817,7 +1839,7 @@ static bool variant_eligible(int v, const ta_conv_launch& p) {
 
 // The automatic choice.
 static int choose_variant(const ta_conv_launch& p) {
-  if (p.uniform_k && p.n_slabs >= 2) {
+  if (p.uniform_k && (p.n_slabs >= 2 || p.prec == PREC_F16)) {
     if (variant_eligible(TA_CV_SPLIT_2x2, p)) {
       if (p.prec != PREC_F32 && p.k_split == 1) {
         // 128 x 256 tiles (8 consumer waves) stream 25 % fewer DMA bytes per FLOP and measure ~8 % faster per tile

@@ -19,7 +19,8 @@ static int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad -
 // A conv may be K-split when it runs on the split-role kernel (uniform K walk; f32 operands in f32 mode, pre-split
 // operands in the bf16 modes) and its epilogue is plain (no residual, no second output).
 static bool conv_ksplit_eligible(const ta_op_desc& op, int in_fmt) {
-  const bool uniform = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
+  const int kblk = in_fmt == TA_FMT_F16 ? 64 : 32;
+  const bool uniform = (op.cin % kblk == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / kblk));
   const bool kernel_ok = in_fmt == ta_split_fmt_of(op.prec);
   return uniform && kernel_ok && op.groups <= 1 && !op.pool;
 }
@@ -194,7 +195,8 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
   }
   for (int i = 0; i < T; ++i) TA_TRY(resolve_alias(i));
   for (int i = 0; i < T; ++i)
-    if (ts[i].fmt != TA_FMT_F32 && ts[i].c % 32) return ta_fail(ctx, TA_E_INVALID, "plan: pre-split tensor %d has %d channels", i, ts[i].c);
+    if ((ts[i].fmt != TA_FMT_F32 && ts[i].c % 32) || (ts[i].fmt == TA_FMT_F16 && ts[i].c % 64) || ts[i].fmt < 0 || ts[i].fmt > TA_FMT_F16)
+      return ta_fail(ctx, TA_E_INVALID, "plan: tensor %d: format %d with %d channels", i, ts[i].fmt, ts[i].c);
 
   // carve the arena
   size_t total = 0;
@@ -235,6 +237,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
     if (op.type != TA_OP_CONV) continue;
     const ta_tensor& ti = ts[op.in];
     np->ktab_off[oi] = ktab.size();
+    if (ti.fmt == TA_FMT_F16) continue;          // split-role kernels only: uniform K walk, no table
     const int cpt = op.cin / 4;
     const int nq = op.kh * op.kw * cpt;
     if (nq > op.n_slabs * 8) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu has too few K slabs", oi);
@@ -365,18 +368,22 @@ int ta_model_run_ops(ta_model* m) {
         p.act = op.act;
         p.stride = op.stride;
         p.prec = op.prec;
-        p.uniform_k = (op.cin % 32 == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / 32));
-        p.k_cblocks = op.cin / 32;
+        // channels per K slab: 32 (float32 and the hi | lo formats: 128 bytes per pixel and slab), 64 in TA_FMT_F16
+        const int kblk = ti.fmt == TA_FMT_F16 ? 64 : 32;
+        p.uniform_k = (op.cin % kblk == 0) && (op.n_slabs == op.kh * op.kw * (op.cin / kblk));
+        p.k_cblocks = op.cin / kblk;
+        if (ti.fmt == TA_FMT_F16 && (!p.uniform_k || op.in_ch_off || op.groups > 1 || op.prec != 4))
+          return ta_fail(ctx, TA_E_INVALID, "op %zu: a half-float tensor feeds whole-tensor convs of the f16 mode only", oi);
         p.k_w = op.kw;
         p.k_h = op.kh;
         p.in_ch_off = op.in_ch_off;
-        p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
-        p.in_row = ti.wp() * ti.c;
-        p.in_pix = ti.c;
-        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.c);
-        p.out_img = (int)((size_t)to.hp() * to.wp() * to.c);
-        p.out_row = to.wp() * to.c;
-        p.out_pix = to.c;
+        p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.cf());
+        p.in_row = ti.wp() * ti.cf();
+        p.in_pix = ti.cf();
+        p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.cf());
+        p.out_img = (int)((size_t)to.hp() * to.wp() * to.cf());
+        p.out_row = to.wp() * to.cf();
+        p.out_pix = to.cf();
         p.out_off0 = (int)to.off(0, 0, 0);
         p.out_ch = op.out_ch_off;
         p.out_fmt = to.fmt;
@@ -384,9 +391,9 @@ int ta_model_run_ops(ta_model* m) {
         if (op.res >= 0) {
           const ta_tensor& tr = m->tensors[op.res];
           p.res = tr.dev;
-          p.res_img = (int)((size_t)tr.hp() * tr.wp() * tr.c);
-          p.res_row = tr.wp() * tr.c;
-          p.res_pix = tr.c;
+          p.res_img = (int)((size_t)tr.hp() * tr.wp() * tr.cf());
+          p.res_row = tr.wp() * tr.cf();
+          p.res_pix = tr.cf();
           p.res_off0 = (int)tr.off(0, 0, 0);
           p.res_ch = op.res_ch_off;
           p.res_fmt = tr.fmt;
@@ -397,9 +404,9 @@ int ta_model_run_ops(ta_model* m) {
           p.out2 = t2.dev;
           p.scale2 = wptr(m, op.scale2_off);
           p.shift2 = wptr(m, op.shift2_off);
-          p.o2_img = (int)((size_t)t2.hp() * t2.wp() * t2.c);
-          p.o2_row = t2.wp() * t2.c;
-          p.o2_pix = t2.c;
+          p.o2_img = (int)((size_t)t2.hp() * t2.wp() * t2.cf());
+          p.o2_row = t2.wp() * t2.cf();
+          p.o2_pix = t2.cf();
           p.o2_off0 = (int)t2.off(0, 0, 0);
           p.o2_ch = op.out2_ch_off;
           p.o2_fmt = t2.fmt;
@@ -509,7 +516,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 6) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 7) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -668,7 +675,11 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
         {
           const int cc = ch_off + c;
           float v;
-          if (t.fmt != TA_FMT_F32) {
+          if (t.fmt == TA_FMT_F16) {
+            _Float16 hh;
+            memcpy(&hh, (const char*)&host[t.off(i, y, x)] + 2 * cc, 2);
+            v = (float)hh;
+          } else if (t.fmt != TA_FMT_F32) {
             const char* b = (const char*)&host[t.off(i, y, x)] + ((cc >> 5) << 7) + ((cc & 31) << 1);
             uint16_t h16, l16;
             memcpy(&h16, b, 2);

@@ -227,9 +227,10 @@ struct ta_tensor {
   bool owns = true;
   int hp() const { return h + 2 * halo; }
   int wp() const { return w + 2 * halo; }
-  size_t elems() const { return (size_t)n * hp() * wp() * c; }
+  size_t elems() const { return (size_t)n * hp() * wp() * c; }            // allocation: 4 bytes per element in every format
+  int cf() const { return fmt == 3 /* TA_FMT_F16 */ ? c / 2 : c; }           // float slots per pixel (what strides are counted in)
   // element offset of interior pixel (img, y, x), channel 0
-  size_t off(int img, int y, int x) const { return (((size_t)img * hp() + y + halo) * wp() + x + halo) * c; }
+  size_t off(int img, int y, int x) const { return (((size_t)img * hp() + y + halo) * wp() + x + halo) * cf(); }
 };
 
 struct ta_conv_launch {
@@ -278,7 +279,7 @@ struct ta_conv_launch {
 };
 
 // the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
-static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : ((prec == 3 || prec == 4) ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */); }
+static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : (prec == 4 ? 3 /* TA_FMT_F16 */ : (prec == 3 ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */)); }
 
 // K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
 // 128 x 128 at the batch sizes in use): K is cut in a FIXED number of ranges that depends on the layer only, never on

@@ -31,17 +31,17 @@ HEADER_DT = np.dtype({
     'itemsize': 128,
 })
 TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
-FMT_F32, FMT_SPLIT, FMT_SPLIT16 = 0, 1, 2
+FMT_F32, FMT_SPLIT, FMT_SPLIT16, FMT_F16 = 0, 1, 2, 3
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
            'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'wscale_log2']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 6            # 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+BLOB_VERSION = 7            # 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3, 'f16': 4}
-SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16, 4: FMT_SPLIT16}     # pre-split activation format per arithmetic mode
+SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16, 4: FMT_F16}     # pre-split activation format per arithmetic mode
 
 
 def _rup(x, m):
@@ -115,6 +115,8 @@ class Program:
         self.outputs = []
         self.f32_only = set()
         self.allow_split = True
+        self._raw = {}         # op index -> (K x coutp float32, taps, cin_p, coutp) of the 'f16' mode's convs (see blob())
+        self._chunk_at = {}    # weight-region offset -> index into wchunks
         self.lane = 0          # convs emitted while this is 1 / 2 run on that side stream (ta_op_desc.variant bits 17..18)
 
     def tensor(self, channels, halo, alias_of=-1, name=None, f32=False):
@@ -135,6 +137,7 @@ class Program:
     def _w(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         off = self.wbytes
+        self._chunk_at[off] = len(self.wchunks)
         self.wchunks.append(arr.tobytes())
         pad = (-len(self.wchunks[-1])) % 256
         if pad:
@@ -189,6 +192,9 @@ class Program:
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
         wscale = 0
         prec = self.prec if precision is None else PRECISIONS[precision]      # a single op may run in another arithmetic mode
+        raw = None
+        if prec == 4:
+            raw = (flat[:K].copy(), kh * kw, cin_p, coutp)       # re-packed in blob() when the input turns out to be TA_FMT_F16
         if prec in (3, 4):
             packed, wscale = split_f16_rows(packed)
         elif prec != 0:
@@ -212,6 +218,8 @@ class Program:
                   scale2_off=scale2_off9 if bias9 is not None else vec(scale2),
                   shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
+        if raw is not None:
+            self._raw[len(self.ops)] = raw
         self.ops.append(op)
 
     def dwconv(self, tin, tout, W, bias, *, stride=1, relu=True):
@@ -319,13 +327,18 @@ class Program:
         for t, (c, _, _) in enumerate(self.tensors):
             precs = cprec.get(t, {self.prec})
             p = next(iter(precs)) if len(precs) == 1 else 0
-            fmt.append(SPLIT_FMT[p] if (self.allow_split and c % 32 == 0) else FMT_F32)
+            fmt.append(SPLIT_FMT[p] if (self.allow_split and c % (64 if p == 4 else 32) == 0) else FMT_F32)
         for t in self.f32_only | {self.input_tensor}:
             fmt[t] = FMT_F32
         for op in self.ops:
             if op['type'] == OP_CONV:
+                taps = op['kh'] * op['kw']
                 pipe = (op['cin'] % 32 == 0 and op['in_ch_off'] % 32 == 0 and op['coutp'] % 64 == 0
-                        and op['n_slabs'] >= 2 and op['n_slabs'] == op['kh'] * op['kw'] * (op['cin'] // 32))
+                        and op['n_slabs'] >= 2 and op['n_slabs'] == taps * (op['cin'] // 32))
+                if op['prec'] == 4:                          # half-float tensors: whole-tensor reads in slabs of 64 channels
+                    k64 = op['cin'] % 64 == 0 and op['n_slabs'] == taps * (op['cin'] // 64)      # already re-packed by blob()
+                    pipe = (pipe or (k64 and op['coutp'] % 64 == 0)) and \
+                        op['cin'] % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
                 if not pipe:
                     fmt[op['in']] = FMT_F32
             elif op['type'] in (OP_DWPW, OP_RFSTEM):            # float32 in, float32 out
@@ -356,6 +369,20 @@ class Program:
         fmts = self.tensor_formats()
         for i, (c, h, a) in enumerate(self.tensors):
             tens[i] = (c, h, a, fmts[i])
+        # 'f16' mode: a conv whose input tensor is stored as plain half floats (TA_FMT_F16) walks K in slabs of 64 channels --
+        # a slab row is 64 halfs of ONE operand, not [hi x32 | lo x32] -- so its weights are re-packed here, in place (half
+        # the bytes of the [hi | lo] image conv() reserved), once the formats are known
+        for i, (flat, taps, cin_p, coutp) in self._raw.items():
+            op = self.ops[i]
+            if fmts[op['in']] != FMT_F16:
+                continue
+            assert cin_p % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
+            K = taps * cin_p
+            rows = np.ldexp(flat.reshape(K // 64, 64, coutp).transpose(0, 2, 1), op['wscale_log2']).astype(np.float16)   # [slab][cout][64]
+            k = self._chunk_at[op['w_off']]
+            assert rows.nbytes * 2 == len(self.wchunks[k])
+            self.wchunks[k] = rows.tobytes() + b'\0' * rows.nbytes
+            op['n_slabs'] = K // 64
         ops = np.zeros(len(self.ops), OP_DT)
         for i, op in enumerate(self.ops):
             for k, v in op.items():
@@ -580,7 +607,8 @@ def pack_arcface(sd, precision='f32'):
         Wl = Wl * s0[chan][None, :]
         A = P.tensor(7 * 7 * 512, 0, alias_of=R)
     E = P.tensor(512, 0, name='embedding', f32=True)
-    P.conv(A, E, Wl.reshape(512, 7 * 7 * 512, 1, 1), bl, ch_pos=ch_pos, pad=0)
+    # f16 mode: 392 slabs of 64 channels -- below the library's own K-split rule (>= 512 slabs), same 32 ranges asked for here
+    P.conv(A, E, Wl.reshape(512, 7 * 7 * 512, 1, 1), bl, ch_pos=ch_pos, pad=0, k_split=32 if P.prec == 4 else 0)
     P.outputs = [E]
     return P
 

@@ -155,7 +155,7 @@ def test_retinaface_front_tile_edges(ctx, states, shape):
 def test_arcface_single_half_mode_within_the_embedding_bar(ctx, states):
     """precision='f16': ONE f16 MFMA per product (operands rounded to 11 bits, f32 accumulate) -- a tolerance mode for the
     embedder only, which takes no discrete decision.  north_star's bar for embeddings is 1e-3 on the unit-norm vector;
-    measured 2.4e-4 worst component (the CPU emulation tests/probe_embed_precision.py predicts 3.0e-4; one bfloat16 per
+    measured 3.6e-4 worst component with 2-byte half-float activations (TA_FMT_F16; the CPU emulation tests/probe_embed_precision.py predicts 3.0e-4; one bfloat16 per
     operand gives 2e-3).  The same packers map 'f16' to 'f16x3' for the detector and the pose network."""
     from terran_amd import ArcFace, lib
     from oracle import nets, pipeline
