@@ -169,6 +169,26 @@ def test_c3_fullsize_crops_vs_oracle(states, precision):
     assert err <= (2e-4 if precision == 'bf16x3' else 2e-5) and unit <= (5e-5 if precision == 'bf16x3' else 5e-6)
 
 
+def test_c3_fullsize_crops_single_half_embedder(states):
+    """configs[2] in the 'f16' mode (one f16 MFMA per product on 2-byte half-float activations; the embedder takes no
+    discrete decision): north_star's bar for embeddings, 1e-3 on the unit-norm vector, at the full 256-crop batch."""
+    import torch
+    from oracle import nets, arcface_pre
+    from terran_amd import ArcFace
+    sd = states('arcface')
+    arc = ArcFace(device=0, state=sd, precision='f16')
+    crops = np.random.default_rng(2).integers(0, 256, (256, 3, 112, 112), dtype=np.uint8)
+    pick = [0, 1, 63, 64, 127, 128, 200, 255]
+    ref = arcface_pre.l2_normalize(nets.arcface_forward(sd, torch.from_numpy(crops[pick].astype(np.float32))).numpy())
+    got = arc.embed_crops(crops)
+    unit = float(np.abs(got[pick] - ref).max())
+    cos = float((1.0 - (got[pick] * ref).sum(1)).max())
+    print('C3 f16 embedder: unit embeddings max abs err %.2e, max cosine distance %.2e' % (unit, cos))
+    assert unit <= 1e-3 and cos <= 1e-5
+    again = arc.embed_crops(crops[:64])                               # batch-invariant: the K split is fixed per layer
+    assert np.array_equal(again, got[:64])
+
+
 @pytest.mark.parametrize('prefer', ['auto', 'split_2x4', 'split_2x2', 'pipe64'])
 def test_c4_fullsize_image_vs_oracle(states, precision, prefer):
     """configs[3]: one 368x656 frame that carries 6 people (decoder weights): PAFs / heat-maps vs the oracle's network,

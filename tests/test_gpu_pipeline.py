@@ -25,15 +25,25 @@ SCORE_TOL = 2e-5                           # probabilities (measured <= 2.1e-6)
 EMB_TOL = 5e-5                             # unit-norm embedding components (measured <= 9e-7 in f32, 3.9e-6 in bf16x3)
 
 
+class _EmbTol(float):
+    """EMB_TOL for the float32-grade modes; in the 'f16' mode (single-half embedder: a tolerance mode for that one task) the
+    bar is north_star's own 1e-3 (measured 3.6e-4).  Set by the `precision` fixture."""
+
+
+_emb = {'tol': EMB_TOL}
+
+
 @pytest.fixture(scope='module')
 def ctx():
     from terran_amd import runtime
     return runtime.get_context(0)
 
 
-@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3'])
+@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3', 'f16'])
 def precision(request):
-    """Both parity-grade conv modes must pass every wrapper / facade test (bf16x3 is bench.py's headline mode)."""
+    """Every parity-grade conv mode must pass every wrapper / facade test (f16x3 is bench.py's headline mode); 'f16' = f16x3
+    for the detector and the pose network + the single-half embedder, held to north_star's 1e-3 on embeddings."""
+    _emb['tol'] = 1e-3 if request.param == 'f16' else EMB_TOL
     return request.param
 
 
@@ -153,15 +163,15 @@ def test_arcface_call(arc, states):
     frames = arc.ctx.upload(image[None])
     feats, crops = arc.embed_faces(frames, [0, 0, 0], [arcface.align_matrix(l) for l in lms], return_crops=True)
     assert np.array_equal(crops, g['crops'])                      # uint8 aligned crops bit-exact vs PIL
-    _near(feats, g['features'], EMB_TOL, 'embed_faces vs reference wrapper')
+    _near(feats, g['features'], _emb['tol'], 'embed_faces vs reference wrapper')
     out = arc.call([image], [[{'landmarks': l} for l in lms]])
     assert len(out) == 1 and out[0].dtype == np.float32
-    _near(out[0], g['features'], EMB_TOL, 'ArcFace.call vs reference wrapper')
+    _near(out[0], g['features'], _emb['tol'], 'ArcFace.call vs reference wrapper')
     np.testing.assert_allclose(np.linalg.norm(out[0], axis=1), 1.0, atol=1e-5)
     # no landmarks: Pillow-bicubic resize + pad on the device
     small = image[:100, :80]
     nolm = arc.call([small], None)
-    _near(nolm, g['feature_nolm'], EMB_TOL, 'ArcFace.call no landmarks vs reference')
+    _near(nolm, g['feature_nolm'], _emb['tol'], 'ArcFace.call no landmarks vs reference')
     # empty: float64 (0,512) per image
     empty = arc.call([image, image], [[], []])
     assert [e.shape for e in empty] == [(0, 512), (0, 512)] and str(empty[0].dtype) == str(g['empty_dtype'])
@@ -173,14 +183,17 @@ def test_arcface_call(arc, states):
     ref = pipeline.arcface_call(states('arcface'), [image, img2, image], faces)
     assert [x.shape for x in got] == [x.shape for x in ref]
     for a, b in zip(got, ref):
-        _near(a, b, EMB_TOL, 'ArcFace.call mixed sizes vs oracle')
+        _near(a, b, _emb['tol'], 'ArcFace.call mixed sizes vs oracle')
 
 
 def test_arcface_crops_and_cosine(arc, states, ctx):
     from oracle import nets, arcface_pre
     g = golden('nets_arcface.npz')
     emb = arc.embed_crops(g['crops'], normalize=False)
-    _near(emb / np.abs(g['embeddings']).max(), g['embeddings'] / np.abs(g['embeddings']).max(), EMB_TOL, 'raw embeddings / max|ref|')
+    # the un-normalised vector is not what the wrapper returns (the bar is on unit-norm components): relative to its largest
+    # component the single-half mode's error is ~4x the unit-norm figure
+    _near(emb / np.abs(g['embeddings']).max(), g['embeddings'] / np.abs(g['embeddings']).max(),
+          _emb['tol'] * (5 if arc.precision == 'f16' else 1), 'raw embeddings / max|ref|')
     a = arcface_pre.l2_normalize(np.random.default_rng(1).normal(size=(5, 512)).astype(np.float32))
     b = arcface_pre.l2_normalize(np.random.default_rng(2).normal(size=(7, 512)).astype(np.float32))
     np.testing.assert_allclose(ctx.cosine_distance(a, b), arcface_pre.cosine_distance(a, b), atol=1e-6)
@@ -474,10 +487,10 @@ def test_facade_pose_and_recognition_vs_reference(states, precision):
     rec = Recognition(device=0, state=states('arcface'), precision=precision)
     one = rec(image, {'landmarks': lms[0]})
     assert one.shape == (1, 512)
-    _near(one, g['one'], EMB_TOL, 'Recognition single vs reference')
-    _near(rec(image, [{'landmarks': lms[0]}, {'landmarks': lms[1]}]), g['lst'], EMB_TOL, 'Recognition list vs reference')
+    _near(one, g['one'], _emb['tol'], 'Recognition single vs reference')
+    _near(rec(image, [{'landmarks': lms[0]}, {'landmarks': lms[1]}]), g['lst'], _emb['tol'], 'Recognition list vs reference')
     many = rec([image, image], [[{'landmarks': lms[0]}], []])
-    _near(many[0], g['many0'], EMB_TOL, 'Recognition batch vs reference')
+    _near(many[0], g['many0'], _emb['tol'], 'Recognition batch vs reference')
     assert many[1].shape == (0, 512) and str(many[1].dtype) == str(g['many1_dtype'])
     with pytest.raises(ValueError):
         rec([image, image], [[]])
