@@ -37,7 +37,7 @@ extern "C" {
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
 #define TA_E_OVERFLOW (-4)  /* an addressing limit was hit (ta_openpose_run: more than 65535 peaks of ONE body part in one image) */
-#define TA_E_RANGE (-5)     /* f16x3 arithmetic mode only: an activation left the half-float range (|x| > 65504); no
+#define TA_E_RANGE (-5)     /* f16x3 / f16 arithmetic modes only: an activation left the half-float range (|x| > 65504); no
                              * numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
 
 #define TA_MODEL_RETINAFACE 1
