@@ -1211,20 +1211,25 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
 // pool, no K-split).  The generic drain above spends ~19 lane-instructions per output element on run-time flags and
 // 64-bit addressing and is VALU-issue-bound (tools/conv_trace.py); this one is ~2x leaner.  Same arithmetic, same
 // order, same bits.
-// F16: the tensors are TA_FMT_SPLIT16 (half words); `amax` then collects the largest |x| stored (range flag)
-template <bool F16>
+// F16 (the format kind): 0 = TA_FMT_SPLIT (bf16 words), 1 = TA_FMT_SPLIT16 (half words), 2 = TA_FMT_F16 (plain half floats, one
+// 16-byte chunk per 8 channels); for 1 and 2 `amax` collects the largest |x| stored (range flag)
+template <int F16>
 __device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], float& amax) {
-  unsigned hw[4], lw[4];
+  if constexpr (F16 == 2) {
+    *(uint4*)q = make_uint4(ta_pack_half2(x[0], x[1]), ta_pack_half2(x[2], x[3]), ta_pack_half2(x[4], x[5]), ta_pack_half2(x[6], x[7]));
+  } else {
+    unsigned hw[4], lw[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ta_pack2<F16>(x[2 * i], x[2 * i + 1], hw[i], lw[i]);
-  *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-  if constexpr (F16) {
+    for (int i = 0; i < 4; ++i) ta_pack2<F16 == 1>(x[2 * i], x[2 * i + 1], hw[i], lw[i]);
+    *(uint4*)q = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  }
+  if constexpr (F16 != 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));   // one v_max3_f32 per pair
   }
 }
-template <int BN, int BM, int NT, int ACT, bool RES, bool F16, bool POOL = false, bool OUT2 = RES, bool B9 = false>
+template <int BN, int BM, int NT, int ACT, bool RES, int F16, bool POOL = false, bool OUT2 = RES, bool B9 = false>
 // RES: + shortcut; OUT2: the second (affine) output; POOL: fused 2x2 max-pool; B9: border-class bias (ta_border_class)
 __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
   constexpr int NCH = BN / 4;
@@ -1246,7 +1251,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     *(f32x4*)sh = *(const f32x4*)(p.shift2 + co);
     *(f32x4*)(sh + 4) = *(const f32x4*)(p.shift2 + co + 4);
   }
-  auto chan = [](int ch) { return ta_split_chan(ch); };
+  auto chan = [](int ch) { return F16 == 2 ? (unsigned)(2 * ch) : ta_split_chan(ch); };
   const float us = p.w_unscale;
   float amax = 0.f;
   char* const ob = (char*)p.out + chan(p.out_ch + co);
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
       const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
       const char* rs = rb + 4u * (unsigned)(img * p.res_img + ry * p.res_row + rx * p.res_pix + p.res_off0);
       *(uint4*)rh = *(const uint4*)rs;
-      *(uint4*)rl = *(const uint4*)(rs + 64);
+      if (F16 != 2) *(uint4*)rl = *(const uint4*)(rs + 64);
     }
     float bb[8];
 #pragma unroll
@@ -1288,7 +1293,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (F16) v[e] = __builtin_fmaf(v[e], us, bb[e]);      // weights were packed times 2^wscale_log2
+      if (F16 != 0) v[e] = __builtin_fmaf(v[e], us, bb[e]);      // weights were packed times 2^wscale_log2
       else v[e] += bb[e];
       if (ACT == TA_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
       if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
@@ -1296,9 +1301,9 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     if (RES) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float h0, h1, l0, l1;
-        ta_unpack2<F16>(rh[i], h0, h1);
-        ta_unpack2<F16>(rl[i], l0, l1);
+        float h0, h1, l0 = 0.f, l1 = 0.f;
+        ta_unpack2<F16 != 0>(rh[i], h0, h1);
+        if (F16 != 2) ta_unpack2<F16 != 0>(rl[i], l0, l1);
         v[2 * i] += h0 + l0;
         v[2 * i + 1] += h1 + l1;
       }
@@ -1336,12 +1341,12 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
       }
     }
   }
-  if constexpr (F16) {
+  if constexpr (F16 != 0) {
     if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
   }
 }
 // picks the lean drain when the launch qualifies; false = run the generic one
-template <int BN, int BM, int NT, bool F16>
+template <int BN, int BM, int NT, int F16>
 __device__ __forceinline__ bool conv_drain_dispatch(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid, int HoWo) {
   if (!p.fast_drain) return false;
   if (p.pool) {
@@ -1503,7 +1508,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
       bool done = false;
-      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), prec_half(PREC)>(p, lds, ct0, pt0, tid, HoWo);
+      if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), (PREC == PREC_F16 ? 2 : (prec_half(PREC) ? 1 : 0))>(p, lds, ct0, pt0, tid, HoWo);
       if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
     }
     return;
@@ -1635,7 +1640,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(7);                     // consumer: past E1
     bool done = false;
-    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), prec_half(PREC)>(p, lds, ct0, pt0, tid, HoWo);
+    if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), (PREC == PREC_F16 ? 2 : (prec_half(PREC) ? 1 : 0))>(p, lds, ct0, pt0, tid, HoWo);
     if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   } else {
     conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
@@ -1713,7 +1718,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;      // tools: A/B
     const long long n_img = p.Ho * p.Wo > 0 ? ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo) : 0;
     auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
-    constexpr int SPLIT_FMT = PREC == PREC_F16 ? -1 : (prec_half(PREC) ? TA_FMT_SPLIT16 : TA_FMT_SPLIT);   // -1: TA_FMT_F16 tensors take the generic drain
+    constexpr int SPLIT_FMT = PREC == PREC_F16 ? TA_FMT_F16 : (prec_half(PREC) ? TA_FMT_SPLIT16 : TA_FMT_SPLIT);
     bool ok = !no_fast_drain && PREC != PREC_F32 && p.k_split == 1 && !p.direct_epilogue && p.out_fmt == SPLIT_FMT &&
               (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
     if (p.res) ok = ok && p.res_fmt == SPLIT_FMT && fits(p.res_img, p.res_off0);
