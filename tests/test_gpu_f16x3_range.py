@@ -66,7 +66,8 @@ def test_range_flag_is_raised_by_the_epilogue_and_cleared(ctx):
         assert _forward_checked(ctx, lib.Model(ctx, _two_convs(prec, 2.0 ** 20)), frames) == lib.OK
 
 
-def test_split_role_epilogues_raise_the_flag(ctx):
+@pytest.mark.parametrize('mode', ['f16x3', 'f16'])
+def test_split_role_epilogues_raise_the_flag(ctx, mode):
     """The lean (conv_drain_fast) and the generic LDS-staged drains of the split-role kernel: a 64 -> 64 conv whose
     OUTPUT is a split tensor beyond the range."""
     from terran_amd import lib
@@ -75,7 +76,7 @@ def test_split_role_epilogues_raise_the_flag(ctx):
     for act, gain, last_gain, expect in ((pack.ACT_RELU, 1.0, 1.0, lib.OK), (pack.ACT_RELU, 2.0 ** 22, None, lib.E_RANGE),
                                          (pack.ACT_NONE, -2.0 ** 22, None, lib.E_RANGE), (pack.ACT_PRELU, 2.0 ** 22, None, lib.E_RANGE),
                                          (pack.ACT_RELU, 1.0, 2.0 ** 22, lib.E_RANGE)):      # last: the float32 output, generic drain
-        P = pack.Program(pack.MODEL_OPENPOSE, 'f16x3')
+        P = pack.Program(pack.MODEL_OPENPOSE, mode)               # 'f16': the same flag on 2-byte half-float tensors
         t0 = P.tensor(4, 1)
         P.input_tensor = t0
         t1 = P.tensor(64, 1, name='mid')
@@ -119,7 +120,8 @@ def test_openpose_wrapper_falls_back_to_f32(states):
     assert c.fallbacks == 0
 
 
-def test_arcface_wrapper_falls_back_to_f32(states):
+@pytest.mark.parametrize('mode', ['f16x3', 'f16'])
+def test_arcface_wrapper_falls_back_to_f32(states, mode):
     from terran_amd import ArcFace
     sd = dict(states('arcface'))
     g = np.float32(2.0 ** 22)
@@ -129,7 +131,7 @@ def test_arcface_wrapper_falls_back_to_f32(states):
     sd['stages.0.0.body.0.running_mean'] = np.asarray(sd['stages.0.0.body.0.running_mean'], np.float32) * g
     sd['stages.0.0.body.0.running_var'] = np.asarray(sd['stages.0.0.body.0.running_var'], np.float32) * g * g
     crops = np.random.default_rng(8).integers(0, 256, (5, 3, 112, 112), dtype=np.uint8)
-    a = ArcFace(device=0, state=sd, precision='f16x3')
+    a = ArcFace(device=0, state=sd, precision=mode)
     b = ArcFace(device=0, state=sd, precision='f32')
     ea, eb = a.embed_crops(crops), b.embed_crops(crops)
     assert a.fallbacks == 1 and np.array_equal(ea, eb) and np.isfinite(ea).all()
