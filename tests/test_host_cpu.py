@@ -381,3 +381,35 @@ def test_detector_lanes_are_closed_branches(monkeypatch):
     Q = pack.pack_retinaface(sd, 'f16x3')
     assert {(op['variant'] >> 17) & 3 for op in Q.ops} == {0} and len(Q.ops) == len(P.ops)
     assert sorted(op['macs_per_pixel'] for op in Q.ops) == sorted(op['macs_per_pixel'] for op in P.ops)
+
+
+def test_f16_mode_packs_half_float_tensors_and_64_channel_slabs():
+    """precision='f16' (single-half embedder): ArcFace's tensors become TA_FMT_F16 (2 bytes per element), every conv that
+    reads one walks K in slabs of 64 channels with weights re-packed as [slab][cout][64 halfs] (x 2^wscale), the stem conv
+    (float32 crops in) keeps 32-wide slabs, the FC asks for its 32 K ranges itself; the detector / pose packers read the
+    mode as 'f16x3'."""
+    from terran_amd import pack, weights
+    sd = weights.make_arcface_state()
+    P = pack.pack_arcface(sd, 'f16')
+    blob = P.blob()
+    fmt = P.tensor_formats()
+    assert fmt[P.input_tensor] == pack.FMT_F32 and fmt[P.outputs[0]] == pack.FMT_F32
+    assert sum(f == pack.FMT_F16 for f in fmt) == len(fmt) - 2          # everything but the float32 crops and the embedding
+    hdr = np.frombuffer(blob[:pack.HEADER_DT.itemsize], pack.HEADER_DT)[0]
+    wreg = blob[int(hdr['weights_off']):]
+    for i, op in enumerate(P.ops):
+        assert op['prec'] == 4
+        taps = op['kh'] * op['kw']
+        if fmt[op['in']] == pack.FMT_F16:
+            assert op['cin'] % 64 == 0 and op['n_slabs'] == taps * op['cin'] // 64
+        else:
+            assert i == 0 and op['n_slabs'] == 2                            # the stem: 27 -> 36 -> 2 slabs of 32
+    op = P.ops[3]                                                           # a 64 -> 64 3x3 conv on a half-float tensor
+    flat, taps, cin_p, coutp = P._raw[3]
+    rows = np.frombuffer(wreg[op['w_off']:op['w_off'] + op['n_slabs'] * coutp * 128], np.float16).reshape(op['n_slabs'], coutp, 64)
+    want = np.ldexp(flat.reshape(-1, 64, coutp).transpose(0, 2, 1), op['wscale_log2']).astype(np.float16)
+    assert np.array_equal(rows, want) and 2.0 ** 13 <= np.abs(rows.astype(np.float32)).max() < 2.0 ** 14
+    assert (P.ops[-1]['variant'] >> 8) & 255 == 32 and P.ops[-1]['n_slabs'] == 392
+    for packer, state in ((pack.pack_retinaface, weights.make_retinaface_state()), (pack.pack_openpose, weights.make_openpose_state())):
+        precs = {o['prec'] for o in packer(state, 'f16').ops if o['type'] == pack.OP_CONV}
+        assert 4 not in precs and 3 in precs
