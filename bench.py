@@ -90,8 +90,8 @@ def conv_roofline(precision, conv):
         'launches_per_step': conv['launches'],
         'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
         'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
-        'mfma_flops_per_algorithmic_flop': factor,
-        'mfma_issue_frac': round(achieved * factor / peak, 4),
+        'mfma_flops_per_algorithmic_flop': factor if precision != 'f16' else '3 (detector, pose) / 1 (embedder)',
+        'mfma_issue_frac': round(achieved * factor / peak, 4) if precision != 'f16' else None,
         'source': 'driver-run: HIP events around every conv launch of one serial step of this very process',
     }
     # The fields below are NOT measured by this run: they replay the builder's rocprofv3 --pmc passes of the same
