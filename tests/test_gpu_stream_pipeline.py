@@ -25,12 +25,13 @@ def _same(a, b):
                 assert np.array_equal(p, q)
 
 
-@pytest.mark.parametrize('devices,inflight', [([0, 0], 2), ([0], 1), ([0, 0, 0], 1)])
-def test_stream_pipeline_equals_one_device_facades(states, devices, inflight):
+@pytest.mark.parametrize('devices,inflight,embed', [([0, 0], 2, None), ([0], 1, None), ([0, 0, 0], 1, None), ([0, 0], 2, 'f16')])
+def test_stream_pipeline_equals_one_device_facades(states, devices, inflight, embed):
+    """embed='f16': the embedder in its single-half mode (batch-invariant like every other mode: the comparison stays exact)."""
     from terran_amd import Detection, Estimation, Recognition
     from terran_amd.pipeline import StreamPipeline
     sd_r, sd_a, sd_p = states('retinaface'), states('arcface'), states('openpose_decoder')
-    kw = dict(detection_kw=dict(short_side=96, state=sd_r), recognition_kw=dict(state=sd_a),
+    kw = dict(detection_kw=dict(short_side=96, state=sd_r), recognition_kw=dict(state=sd_a, precision=embed),
               estimation_kw=dict(short_side=96, state=sd_p))
     sizes = [5, 4, 1, 2, 7, 3]                               # odd sizes, fewer frames than replicas
     batches = [synth.pose_code_frames(900 + 10 * i, n, 96, 128, 3) for i, n in enumerate(sizes)]
@@ -45,7 +46,7 @@ def test_stream_pipeline_equals_one_device_facades(states, devices, inflight):
                 fr.free()
     finally:
         pipe.close()
-    det, rec, est = (Detection(short_side=96, device=0, state=sd_r), Recognition(device=0, state=sd_a),
+    det, rec, est = (Detection(short_side=96, device=0, state=sd_r), Recognition(device=0, state=sd_a, precision=embed),
                      Estimation(short_side=96, device=0, state=sd_p))
     assert len(got) == len(batches)
     n_det = n_pose = 0
