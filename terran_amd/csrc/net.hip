@@ -150,6 +150,8 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
     TA_TRY(resolve_alias(op.in));
     if (!set[op.in]) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu reads unset tensor %d", oi, op.in);
     const ta_tensor& ti = ts[op.in];
+    if (op.type != TA_OP_CONV && (ti.fmt == TA_FMT_F16 || ts[op.out].fmt == TA_FMT_F16))
+      return ta_fail(ctx, TA_E_INVALID, "plan: op %zu: only convs read and write half-float tensors", oi);
     switch (op.type) {
       case TA_OP_CONV:
         if (op.groups > 1) {   // runs on the split-role kernel only: uniform K walk, 128-channel tiles inside one group

@@ -348,6 +348,10 @@ class Program:
             elif op['type'] == OP_COPYCH:
                 if op['cin'] % 32 or op['in_ch_off'] % 32 or op['out_ch_off'] % 32:
                     fmt[op['in']] = fmt[op['out']] = FMT_F32
+            if op['type'] != OP_CONV:                       # half-float tensors are the conv kernels' alone
+                for t in (op['in'], op['out']):
+                    if fmt[t] == FMT_F16:
+                        fmt[t] = FMT_F32
         changed = True
         while changed:                                  # aliases share memory; copies are raw
             changed = False
