@@ -1,6 +1,7 @@
 """Per-model throughput at SURVEY.md 8's shapes C2 / C3 / C4 (run on the GPU box).
 
-    python tools/model_bench.py [--out gpurun_out/per_model.json] [--precisions f16x3 f32]
+    python tools/model_bench.py [--out gpurun_out/per_model.json] [--precisions f16x3 f32 f16]
+('f16' = the single-half embedder; the detector and the pose network run as f16x3 in that mode)
 
 C2  RetinaFace   32 x 640 x 640   frames resident in HBM -> network + decode + sort + NMS + result download
 C3  ArcFace      256 x 3 x 112 x 112 BGR crops (host)    -> upload + network + L2 norm + download (0.7 MB/crop: PCIe-light)
