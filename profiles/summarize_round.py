@@ -69,7 +69,7 @@ def pmc_total(db_path, counter):
 
 
 def main(collect, prefix, steps=3):
-    for P in ('f16x3', 'f32'):
+    for P in ('f16', 'f16x3', 'f32'):
         kt = find_db(os.path.join(collect, 'kt_' + P))
         out = {}
         if kt:
