@@ -413,3 +413,4 @@ def test_f16_mode_packs_half_float_tensors_and_64_channel_slabs():
     for packer, state in ((pack.pack_retinaface, weights.make_retinaface_state()), (pack.pack_openpose, weights.make_openpose_state())):
         precs = {o['prec'] for o in packer(state, 'f16').ops if o['type'] == pack.OP_CONV}
         assert 4 not in precs and 3 in precs
+        assert packer(state, 'f16').blob() == packer(state, 'f16x3').blob()    # the SAME programs: every decision as in f16x3
