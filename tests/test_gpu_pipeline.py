@@ -41,7 +41,7 @@ def ctx():
 
 @pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3', 'f16'])
 def precision(request):
-    """Every parity-grade conv mode must pass every wrapper / facade test (f16x3 is bench.py's headline mode); 'f16' = f16x3
+    """Every parity-grade conv mode must pass every wrapper / facade test ('f16' is bench.py's headline mode) = f16x3
     for the detector and the pose network + the single-half embedder, held to north_star's 1e-3 on embeddings."""
     _emb['tol'] = 1e-3 if request.param == 'f16' else EMB_TOL
     return request.param
