@@ -17,12 +17,14 @@ measured as well and reported under `other_faces_per_frame`).  Per GPU the host 
 three threads / HIP streams (detect -> queue -> embed, pose); all K steps complete inside the timed region.  Frames
 shard embarrassingly: every rank owns its own batches, there is no data-path collective ("scaling": "weak").
 
-The ONE JSON line rank 0 prints carries, next to the headline (`value`: f16x3 mode -- split-half operands, 22 bits,
-float32-grade results: tests/test_gpu_decisions_vs_oracle.py -- frames resident in HBM):
+The ONE JSON line rank 0 prints carries, next to the headline (`value`: f16x3 mode, the library default -- split-half
+operands, 22 bits, float32-grade results: tests/test_gpu_decisions_vs_oracle.py -- frames resident in HBM):
   value_f32 / roofline_f32      the same workload with every conv on the exact-f32 MFMA (the like-for-like arithmetic)
   value_ingest                  = ingest.value: the figure comparable with the reference's `.call`, whose first act is the
                                 host -> device copy of the batch (retinaface/wrapper.py:144)
-  sustained                     the headline mode again over a >= 2 s timed region (the driver's K may be short)
+  value_k_steps                 the exact K = --steps region (`value` itself is quoted from a region of >= 2.5 s: a 0.25 s
+                                region reads ~8 % above what the loop sustains -- the chip clocks to its power budget)
+  value_f16_embedder            the opt-in tolerance mode: the embedder alone on one f16 MFMA per product (3.6e-4 of a 1e-3 bar)
   ingest                        the same workload fed from HOST memory: a raw rgb24 byte stream read into pinned buffers
                                 and uploaded by video.RawVideoReader threads (upload overlapped with compute), results
                                 gathered in order on rank 0 every step -- the SURVEY.md 8(e) pipeline with its scatter
@@ -60,11 +62,11 @@ PEAKS = {
     'f16': (2500.0, 'v_mfma_f32_32x32x16_f16: x3 (split-half operands) in the detector and the pose network, x1 in the embedder', 3),
 }
 HBM_PEAK_GBPS = 8000.0
-# The mode `value` is measured in: every network that takes discrete decisions (detector, pose) on the float32-grade split-half
-# arithmetic (0 decision flips vs the oracle over 224 frames per task), the embedder -- no decisions, north_star's bar 1e-3 on the
-# unit-norm embedding, measured 3.6e-4 -- on one f16 MFMA per product.  The all-float32-grade figure is `value_f16x3`, the
-# exact-f32-MFMA figure `value_f32`, in the same line.
-HEADLINE = 'f16'
+# The mode `value` is measured in = the LIBRARY DEFAULT (runtime.resolve_precision): every network on the float32-grade split-half
+# arithmetic (x = hi + lo, 22 significant bits, three f16 MFMAs per product; 0 decision flips vs the oracle, embeddings to 5e-7).
+# Beside it in the same line: `value_f16_embedder` (the opt-in tolerance mode: the embedder alone on one f16 MFMA per product,
+# embeddings 3.6e-4 against north_star's 1e-3 bar) and `value_f32` (every conv on the exact-f32 MFMA).
+HEADLINE = 'f16x3'
 DTYPES = {'f32': 'f32',
           'f16x3': 'f16x3 (ArcFace / OpenPose operands x = hi + lo as two IEEE half floats = 22 significant bits, weights '
                    'pre-scaled by a power of two per layer; 3 f16 MFMAs per product term (every product exact), f32 '
@@ -159,7 +161,13 @@ def main():
     ap.add_argument('--window', type=int, default=0,
                     help='bounded run-ahead inside a pipeline: a task starts step i once all three finished step i - W (0 = unbounded)')
     ap.add_argument('--join-steps', action='store_true', help='join the face and pose threads after every step')
-    ap.add_argument('--sustain-seconds', type=float, default=2.5, help='length of the `sustained` timed region')
+    ap.add_argument('--sustain-seconds', type=float, default=2.5,
+                    help='minimum length of the timed region `value` is quoted from (the K-step region is reported beside it)')
+    ap.add_argument('--side-seconds', type=float, default=1.5,
+                    help='minimum length of the timed regions of the side legs (other precisions, faces per frame)')
+    ap.add_argument('--lane-embedders', action='store_true',
+                    help='A/B: one embed thread + ArcFace model per lane (64 crops per launch) instead of one embed worker per '
+                         'device that launches on the faces of several batches')
     ap.add_argument('--single-process', action='store_true',
                     help='--gpus N devices driven by ONE process through the facades\' device-list fan-out')
     ap.add_argument('--devices', default=None, help='with --single-process: comma-separated device ids (repeats allowed)')
@@ -393,9 +401,8 @@ def run(args):
         for p in pipes:
             p.sync()
         if engine.get('sp') is not None:
-            for lane in engine['sp'].lanes[0]:
-                for c in (lane.ctx_up, lane.det.model.ctx, lane.rec.model.ctx, lane.est.model.ctx):
-                    c.sync()
+            for c in engine['sp'].contexts():
+                c.sync()
         if use_dist:
             if backend == 'nccl':
                 torch.cuda.synchronize()
@@ -457,13 +464,13 @@ def run(args):
             c.profile(False)
         return klass
 
-    def run_mode(precision, steps, extra=None):
+    def run_mode(precision, steps, extra=None, min_seconds=0.0):
         """Warm up, time `steps` steps (barrier + sync on both sides, max over ranks), then the profiled serial step.
         extra(result_dict): further legs measured while this mode's models are loaded."""
         for p in pipes:
             p.load(precision)
         if streaming:
-            engine['sp'] = StreamPipeline([device_index], inflight=L, pick_faces=pick_faces,
+            engine['sp'] = StreamPipeline([device_index], inflight=L, pick_faces=pick_faces, shared_embedder=not args.lane_embedders,
                                           detection_kw=dict(short_side=416, state=sd_r, precision=precision),
                                           recognition_kw=dict(state=sd_a, precision=precision),
                                           estimation_kw=dict(short_side=184, state=sd_p, precision=precision))
@@ -471,12 +478,23 @@ def run(args):
         if args.warmup:
             run_steps(args.warmup if not streaming else max(args.warmup, 2 * L))      # every lane warms its plans
         elapsed, out = timed(steps)
-        res = {'elapsed': elapsed, 'out': out, 'klass': profile_serial_step()}
+        res = {'elapsed_k': elapsed, 'steps_k': steps, 'elapsed': elapsed, 'steps': steps, 'out': out}
+        # The chip clocks to its power budget: a region of a few tenths of a second reads ~8 % above what the same loop
+        # sustains.  Every figure of the line therefore comes from a region of >= `min_seconds`; the exact-K region the
+        # driver asked for is reported beside it (`value_k_steps`).  The step count follows from the max-over-ranks time of
+        # the K-step region, so it is the same on every rank.
+        if min_seconds > 0 and elapsed < min_seconds and not (args.serial or args.join_steps):
+            k = int(np.ceil(min_seconds / (elapsed / steps)))
+            e2, out = timed(k)
+            res.update(elapsed=e2, steps=k, out=out)
+        res['klass'] = profile_serial_step()
         if extra:
             extra(res)
         if streaming:
             for fr in engine['resident']:
                 fr.free()
+            n_l, n_c = engine['sp'].embed_stats()
+            res['crops_per_embed_launch'] = n_c / n_l if n_l else 0.0
             engine.pop('sp').close()
         for p in pipes:
             p.unload()
@@ -488,11 +506,6 @@ def run(args):
     def extra_headline(res):
         if args.single_mode or args.serial or args.join_steps:
             return
-        # -- sustained: the same measurement over a region of >= --sustain-seconds
-        per_step = res['elapsed'] / args.steps
-        k = max(args.steps, int(np.ceil(args.sustain_seconds / per_step)))
-        e, _ = timed(k)
-        res['sustained'] = {'steps': k, 'seconds': round(e, 3), 'value': fps(e, k), 'ms_per_step': round(e / k * 1e3, 3)}
         try:
             ingest_leg(res)
         except Exception as ex:                                   # the headline must survive a failing secondary leg
@@ -560,16 +573,16 @@ def run(args):
                     '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or HEADLINE)
-    head = run_mode(primary, args.steps, extra_headline)
-    elapsed, out, klass = head['elapsed'], head['out'], head['klass']
+    head = run_mode(primary, args.steps, extra_headline, min_seconds=0.0 if args.single_mode else args.sustain_seconds)
+    elapsed, steps_timed, out, klass = head['elapsed'], head['steps'], head['out'], head['klass']
     others = {}
     if not args.single_mode:
         for prec in ('f32', 'f16x3', 'bf16x3', 'f16'):
             if prec != primary:
-                steps2 = max(L, args.steps // 2)
-                r2 = run_mode(prec, steps2)
-                others[prec] = {'value': fps(r2['elapsed'], steps2), 'steps': steps2,
-                                'ms_per_step': round(r2['elapsed'] / steps2 * 1e3, 3),
+                r2 = run_mode(prec, max(L, args.steps // 2), min_seconds=args.side_seconds)
+                others[prec] = {'value': fps(r2['elapsed'], r2['steps']), 'steps': r2['steps'],
+                                'timed_region_s': round(r2['elapsed'], 3),
+                                'ms_per_step': round(r2['elapsed'] / r2['steps'] * 1e3, 3),
                                 'roofline': conv_roofline(prec, r2['klass']['conv_igemm'])}
 
     # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
@@ -578,10 +591,10 @@ def run(args):
         for nf in (1, 4):
             if nf != F:
                 face_state['F'] = nf
-                steps3 = max(L, args.steps // 2)
-                r3 = run_mode(primary, steps3)
-                other_faces[str(nf)] = {'value': fps(r3['elapsed'], steps3), 'steps': steps3,
-                                        'ms_per_step': round(r3['elapsed'] / steps3 * 1e3, 3),
+                r3 = run_mode(primary, max(L, args.steps // 2), min_seconds=args.side_seconds)
+                other_faces[str(nf)] = {'value': fps(r3['elapsed'], r3['steps']), 'steps': r3['steps'],
+                                        'timed_region_s': round(r3['elapsed'], 3),
+                                        'ms_per_step': round(r3['elapsed'] / r3['steps'] * 1e3, 3),
                                         'algorithmic_gflop_per_step': round(r3['klass']['conv_igemm']['work'] / 1e9, 1)}
         face_state['F'] = F
 
@@ -590,13 +603,21 @@ def run(args):
         dets, feats, poses = out
         result = {
             'metric': 'frames/sec 1080p detect+embed+pose',
-            'value': fps(elapsed, args.steps),
+            # `value`, `ms_per_step`, `timed_region_s`: the region of >= --sustain-seconds (`timed_steps` steps, barrier + sync on
+            # both sides, max over ranks); the EXACT K = `steps` region the caller asked for, timed the same way right before
+            # it, is `value_k_steps` / `ms_per_step_k_steps` / `timed_region_s_k_steps` (a 0.25 s region reads ~8 % high: the
+            # chip has not settled on its sustained clock yet)
+            'value': fps(elapsed, steps_timed),
             'unit': 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step': round(elapsed / steps_timed * 1e3, 3),
             'timed_region_s': round(elapsed, 3),
+            'timed_steps': steps_timed,
+            'value_k_steps': fps(head['elapsed_k'], head['steps_k']),
+            'ms_per_step_k_steps': round(head['elapsed_k'] / head['steps_k'] * 1e3, 3),
+            'timed_region_s_k_steps': round(head['elapsed_k'], 3),
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -616,21 +637,23 @@ def run(args):
                 'pose_peaks_per_frame': round(pipes[0].ctxs[2].pose_stats()[0] / float(args.batch), 1),
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
-                'streams_per_gpu': 4 * L,
+                'streams_per_gpu': 4 * L if args.lane_embedders else 3 * L + 1,
                 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                 'batches_in_flight_per_gpu': L,
                 'step_overlap': 'serial: one kernel at a time' if args.serial else
                                 'one step at a time' if args.join_steps else
-                                'terran_amd.pipeline.StreamPipeline: %d lanes of upload / detect -> embed / pose host threads '
-                                '(a context = HIP stream each), lane l takes steps l, l+%d, ... (embed consumes the detections '
-                                'of its batch through a queue), results collected in step order; the region ends when the '
-                                'last step is collected' % (L, L),
+                                'terran_amd.pipeline.StreamPipeline: %d lanes of upload / detect / pose host threads (a context = HIP '
+                                'stream each), lane l takes steps l, l+%d, ...; %s; results collected in step order; the region '
+                                'ends when the last step is collected'
+                                % (L, L, 'an embed thread per lane consumes the detections of its batch' if args.lane_embedders else
+                                   'ONE embed worker takes the detections of all lanes and launches ArcFace on the faces of several '
+                                   'batches at once (>= 192 crops or 10 ms; %.0f crops per launch measured)' % head.get('crops_per_embed_launch', 0)),
             },
             'roofline': dict(conv_roofline(primary, klass['conv_igemm']),
                              # the same algorithmic FLOPs over the PIPELINED step (what `value` is made of): above the serial
                              # figure because concurrent streams fill the CUs one kernel's tail and launch gaps leave idle
-                             pipelined_achieved=round(klass['conv_igemm']['work'] / (elapsed / args.steps) / 1e12, 2),
-                             pipelined_frac=round(klass['conv_igemm']['work'] / (elapsed / args.steps) / 1e12 / PEAKS[primary][0], 4)),
+                             pipelined_achieved=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12, 2),
+                             pipelined_frac=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12 / PEAKS[primary][0], 4)),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
             # algorithmic bytes / kernel time of the HBM-bound kernel classes (peak 8000 GB/s); post-processing
             # mixes the pose-map stream with latency-bound selection / grouping kernels
@@ -655,12 +678,12 @@ def run(args):
             result['value_f16x3'] = others['f16x3']['value']
             result['ms_per_step_f16x3'] = others['f16x3']['ms_per_step']
             result['roofline_f16x3'] = others['f16x3']['roofline']
-        if 'f16' in others:                                          # tolerance mode for the embedder alone (see DTYPES['f16'])
+        if 'f16' in others:                                          # opt-in tolerance mode for the embedder alone (see DTYPES['f16'])
             result['value_f16_embedder'] = others['f16']['value']
             result['ms_per_step_f16_embedder'] = others['f16']['ms_per_step']
-        for key in ('sustained', 'ingest'):
-            if key in head:
-                result[key] = head[key]
+            result['roofline_f16_embedder'] = others['f16']['roofline']
+        if 'ingest' in head:
+            result['ingest'] = head['ingest']
         if isinstance(head.get('ingest', {}).get('value'), float):
             result['value_ingest'] = head['ingest']['value']
         result['other_precisions'] = others
@@ -844,7 +867,7 @@ def run_single_process(args):
         return [[{'landmarks': x['landmarks']} for x in d[:F]] + [{'landmarks': fallback_lm[k]} for k in range(len(d[:F]), F)]
                 for d in dets]
     L = max(1, args.inflight)
-    pipe = StreamPipeline(devices, inflight=L, pick_faces=pick,
+    pipe = StreamPipeline(devices, inflight=L, pick_faces=pick, shared_embedder=not args.lane_embedders,
                           detection_kw=dict(short_side=416, state=sd_r, precision=prec),
                           recognition_kw=dict(state=sd_a, precision=prec),
                           estimation_kw=dict(short_side=184, state=sd_p, precision=prec))
@@ -862,7 +885,8 @@ def run_single_process(args):
     elapsed, out = timed((resident for _ in range(args.steps)), args.steps)
     # one batch alone with a HIP event pair around every launch of lane 0 of device 0 -> the per-class times of a step
     lane = pipe.lanes[0][0]
-    ctxs = [lane.det.model.ctx, lane.rec.model.ctx, lane.est.model.ctx]
+    ctxs = [lane.det.model.ctx, lane.est.model.ctx] + ([lane.rec.model.ctx] if lane.rec is not None else
+                                                      [pipe.embedders[runtime.device_index(devices[0])].ctx])
     for c in ctxs:
         c.profile_reset()
         c.profile(True)

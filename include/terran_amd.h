@@ -51,6 +51,9 @@ typedef struct ta_frames ta_frames; /* a batch of uint8 RGB frames resident in H
 /* ---- context -------------------------------------------------------------------------- */
 const char* ta_version(void);
 int ta_device_count(void);
+/* PCI address ("0000:c1:00.0") of a device: what the host side needs to find the NUMA node / local CPUs of a GPU in sysfs
+ * (terran_amd/affinity.py binds a rank's or a lane's host threads and pinned staging to them).  capacity >= 16. */
+int ta_device_pci_bus_id(int device_id, char* out, int capacity);
 int ta_ctx_create(int device_id, ta_ctx** out);
 void ta_ctx_destroy(ta_ctx* ctx);
 const char* ta_last_error(const ta_ctx* ctx);
@@ -132,6 +135,13 @@ int ta_arcface_embed_crops(ta_model* m, const uint8_t* crops_nchw_bgr, int n, in
 int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* frame_index,
                            const double* inv_affine, int n, int normalize, float* out,
                            uint8_t* crops_out);
+/* The same for faces cut from SEVERAL resident frame batches in one launch (a video loop's embedder sees the faces of every
+ * batch in flight: the network fills the chip at ~256 crops, one 32-frame batch brings ~64): face k comes from
+ * frames[source_index[k]] (source_index NULL: all from frames[0]), image frame_index[k] of that batch.  All batches must live
+ * on the model's device (any context).  A face's embedding does not depend on the launch it rides in. */
+int ta_arcface_embed_faces_multi(ta_model* m, const ta_frames* const* frames, int n_sources, const int32_t* source_index,
+                                 const int32_t* frame_index, const double* inv_affine, int n, int normalize,
+                                 float* out, uint8_t* crops_out);
 /* Cosine distance matrix 1 - a.b/(|a||b|) (examples/match.py:38): a (na,dim), b (nb,dim) -> (na,nb). */
 int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int nb, int dim, float* out);
 

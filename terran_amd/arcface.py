@@ -76,6 +76,40 @@ class ArcFace(runtime.RangeFallback):
             model.h, frames.h, lib.ptr(idx), lib.ptr(mats), n, int(normalize), lib.ptr(out), lib.ptr(crops))))
         return (out, crops) if return_crops else out
 
+    def embed_faces_multi(self, frames_list, source_index, frame_index, matrices, normalize=True):
+        """Faces cut from SEVERAL resident batches in one launch: face k comes from frames_list[source_index[k]], image
+        frame_index[k] of it (ta_arcface_embed_faces_multi)."""
+        import ctypes
+        src = np.ascontiguousarray(source_index, dtype=np.int32)
+        idx = np.ascontiguousarray(frame_index, dtype=np.int32)
+        mats = np.ascontiguousarray(matrices, dtype=np.float64).reshape(-1, 6)
+        n = idx.shape[0]
+        out = np.empty((n, 512), np.float32)
+        handles = (ctypes.c_void_p * len(frames_list))(*[f.h for f in frames_list])
+        self._with_fallback(lambda model: self.ctx.check(self.ctx.lib.ta_arcface_embed_faces_multi(
+            model.h, handles, len(frames_list), lib.ptr(src), lib.ptr(idx), lib.ptr(mats), n, int(normalize), lib.ptr(out), None)))
+        return out
+
+    def call_multi(self, items):
+        """items: [(lib.Frames, faces_per_image), ...] -> [what `call(frames, faces_per_image)` returns, ...], all faces of
+        all items embedded in ONE launch (terran_amd.pipeline's embed worker)."""
+        counts = [[len(f) for f in faces] for _, faces in items]
+        if sum(sum(c) for c in counts) == 0:
+            return [[np.empty((0, 512)) for _ in c] for c in counts]
+        lms = np.array([face['landmarks'] for _, faces in items for f in faces for face in f])
+        src = np.concatenate([np.full(sum(c), s, np.int32) for s, c in enumerate(counts)])
+        idx = np.concatenate([np.repeat(np.arange(len(c)), c) for c in counts])
+        feats = self.embed_faces_multi([fr for fr, _ in items], src, idx, align_matrices(lms))
+        out, o = [], 0
+        for c in counts:
+            n = sum(c)
+            if n == 0:
+                out.append([np.empty((0, 512)) for _ in c])                 # float64, as wrapper.py:160-164
+            else:
+                out.append(np.split(feats[o:o + n], np.cumsum(c)[:-1], axis=0))
+            o += n
+        return out
+
     # -- the reference call ------------------------------------------------------------------
     def call(self, images, faces_per_image=None):
         """images: list of (H_i,W_i,3) uint8 RGB (or an (N,H,W,3) array); faces_per_image: list of

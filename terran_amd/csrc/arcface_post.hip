@@ -6,16 +6,24 @@
 //  * row-wise L2 normalisation (sklearn normalize, wrapper.py:176) as one wavefront per row;
 //  * cosine distance matrix (examples/match.py:38).
 // Compiled with -ffp-contract=off: the float64 warp must round exactly like Pillow's C code.
+#include <string.h>
+
 #include "ta_internal.h"
 
-__global__ __launch_bounds__(256) void warp_kernel(const uint8_t* frames, int H, int W, const int32_t* frame_index,
-                                                    const double* inv_affine, int n, uint8_t* crops) {
+// face k is cut from the image at src[k].img (H x W x 3 uint8 RGB): the faces of one launch may come from several frame
+// batches (ta_arcface_embed_faces_multi), each with its own size
+struct ta_warp_src {
+  const uint8_t* img;
+  int32_t H, W;
+};
+__global__ __launch_bounds__(256) void warp_kernel(const ta_warp_src* src, const double* inv_affine, int n, uint8_t* crops) {
   const int total = n * 112 * 112;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int k = i / (112 * 112);
     const int rem = i - k * 112 * 112;
     const int oy = rem / 112, ox = rem - oy * 112;
     const double* a = inv_affine + 6 * k;
+    const int H = src[k].H, W = src[k].W;
     const double xin = (double)ox + 0.5, yin = (double)oy + 0.5;
     double sx = a[0] * xin + a[1] * yin + a[2];
     double sy = a[3] * xin + a[4] * yin + a[5];
@@ -34,7 +42,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* frames, int H,
     const int x1 = x + 1 < 0 ? 0 : (x + 1 < W ? x + 1 : W - 1);
     const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
     const bool row2 = (y + 1 >= 0) && (y + 1 < H);
-    const uint8_t* img = frames + (size_t)frame_index[k] * H * W * 3;
+    const uint8_t* img = src[k].img;
     const uint8_t* r0 = img + (size_t)yc * W * 3;
     const uint8_t* r1 = img + (size_t)(row2 ? y + 1 : yc) * W * 3;
 #pragma unroll
@@ -115,36 +123,54 @@ int ta_arcface_embed_crops(ta_model* m, const uint8_t* crops, int n, int normali
   return embed_tail(m, n, normalize, out);
 }
 
-int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* frame_index, const double* inv_affine,
-                           int n, int normalize, float* out, uint8_t* crops_out) {
+int ta_arcface_embed_faces_multi(ta_model* m, const ta_frames* const* frames, int n_sources, const int32_t* source_index,
+                                 const int32_t* frame_index, const double* inv_affine, int n, int normalize, float* out,
+                                 uint8_t* crops_out) {
   ta_enter(m ? m->ctx : nullptr);
-  if (!m || !frames || n < 0 || (n > 0 && (!frame_index || !inv_affine || !out))) return TA_E_INVALID;
+  if (!m || !frames || n_sources <= 0 || n < 0 || (n > 0 && (!frame_index || !inv_affine || !out))) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->kind != TA_MODEL_ARCFACE) return ta_fail(ctx, TA_E_INVALID, "arcface: wrong model kind");
   if (n == 0) return TA_OK;
-  for (int k = 0; k < n; ++k)
-    if (frame_index[k] < 0 || frame_index[k] >= frames->n) return ta_fail(ctx, TA_E_INVALID, "arcface: frame_index[%d] out of range", k);
+  for (int s = 0; s < n_sources; ++s)
+    if (!frames[s] || frames[s]->ctx->device != ctx->device) return ta_fail(ctx, TA_E_INVALID, "arcface: frame batch %d is null or lives on another device", s);
   TA_TRY(ta_model_plan(m, n, 112, 112));
   const size_t crop_bytes = (size_t)n * 3 * 112 * 112;
   const size_t aff_off = (crop_bytes + 255) & ~(size_t)255;
-  const size_t idx_off = aff_off + (((size_t)n * 48 + 255) & ~(size_t)255);
+  const size_t src_off = aff_off + (((size_t)n * 48 + 255) & ~(size_t)255);
   char* scr = nullptr;
-  TA_TRY(ta_scratch(ctx, idx_off + (size_t)n * 4, (void**)&scr));
-  TA_HIP(ctx, hipMemcpyAsync(scr + aff_off, inv_affine, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream));
-  TA_HIP(ctx, hipMemcpyAsync(scr + idx_off, frame_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  char* stage = nullptr;                          // pinned: the two tables travel in one async copy
+  TA_TRY(ta_scratch(ctx, src_off + (size_t)n * sizeof(ta_warp_src), (void**)&scr));
+  TA_TRY(ta_pinned(ctx, (src_off - aff_off) + (size_t)n * sizeof(ta_warp_src), (void**)&stage));
+  memcpy(stage, inv_affine, (size_t)n * 48);
+  ta_warp_src* srcs = (ta_warp_src*)(stage + (src_off - aff_off));
+  for (int k = 0; k < n; ++k) {
+    const int s = source_index ? source_index[k] : 0;
+    if (s < 0 || s >= n_sources) return ta_fail(ctx, TA_E_INVALID, "arcface: source_index[%d] out of range", k);
+    const ta_frames* f = frames[s];
+    if (frame_index[k] < 0 || frame_index[k] >= f->n) return ta_fail(ctx, TA_E_INVALID, "arcface: frame_index[%d] out of range", k);
+    srcs[k].img = f->dev + (size_t)frame_index[k] * f->h * f->w * 3;
+    srcs[k].H = f->h;
+    srcs[k].W = f->w;
+  }
+  TA_HIP(ctx, hipMemcpyAsync(scr + aff_off, stage, (src_off - aff_off) + (size_t)n * sizeof(ta_warp_src), hipMemcpyHostToDevice, ctx->stream));
   {
     ta_prof_scope scope(ctx, 2, (double)crop_bytes * 5);
     int g = (n * 112 * 112 + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(warp_kernel, dim3(g), dim3(256), 0, ctx->stream, frames->dev, frames->h, frames->w,
-                       (const int32_t*)(scr + idx_off), (const double*)(scr + aff_off), n, (uint8_t*)scr);
+    hipLaunchKernelGGL(warp_kernel, dim3(g), dim3(256), 0, ctx->stream, (const ta_warp_src*)(scr + src_off),
+                       (const double*)(scr + aff_off), n, (uint8_t*)scr);
     TA_HIP(ctx, hipGetLastError());
   }
   TA_TRY(ta_launch_preprocess(ctx, TA_PRE_ARCFACE_CROPS, (const uint8_t*)scr, n, 112, 112, m->tensors[m->hdr.input_tensor]));
   TA_TRY(ta_model_run_ops(m));
   if (crops_out) TA_HIP(ctx, hipMemcpyAsync(crops_out, scr, crop_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return embed_tail(m, n, normalize, out);
+}
+
+int ta_arcface_embed_faces(ta_model* m, const ta_frames* frames, const int32_t* frame_index, const double* inv_affine,
+                           int n, int normalize, float* out, uint8_t* crops_out) {
+  if (!frames) return TA_E_INVALID;
+  return ta_arcface_embed_faces_multi(m, &frames, 1, nullptr, frame_index, inv_affine, n, normalize, out, crops_out);
 }
 
 int ta_cosine_distance(ta_ctx* ctx, const float* a, int na, const float* b, int nb, int dim, float* out) {

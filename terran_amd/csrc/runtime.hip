@@ -107,6 +107,15 @@ int ta_device_count(void) {
   return n;
 }
 
+int ta_device_pci_bus_id(int device_id, char* out, int capacity) {
+  if (!out || capacity < 16) return TA_E_INVALID;
+  out[0] = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return TA_E_DEVICE;
+  if (hipDeviceGetPCIBusId(out, capacity, device_id) != hipSuccess) return TA_E_DEVICE;
+  return TA_OK;
+}
+
 int ta_ctx_create(int device_id, ta_ctx** out) {
   if (!out) return TA_E_INVALID;
   *out = nullptr;

@@ -30,6 +30,7 @@ u8p, i32p, f32p, f64p = P(C.c_uint8), P(C.c_int32), P(C.c_float), P(C.c_double)
 SIGNATURES = {
     'ta_version': (C.c_char_p, []),
     'ta_device_count': (c_int, []),
+    'ta_device_pci_bus_id': (c_int, [c_int, C.c_char_p, c_int]),
     'ta_ctx_create': (c_int, [c_int, P(c_void_p)]),
     'ta_ctx_destroy': (None, [c_void_p]),
     'ta_last_error': (C.c_char_p, [c_void_p]),
@@ -62,6 +63,8 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p, P(C.c_int32)]),
     'ta_arcface_embed_crops': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'ta_arcface_embed_faces': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'ta_arcface_embed_faces_multi': (c_int, [c_void_p, P(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                             c_void_p]),
     'ta_cosine_distance': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ta_openpose_run': (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, P(C.c_int32)]),
     'ta_openpose_group': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p,

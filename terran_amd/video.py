@@ -65,7 +65,10 @@ class RawVideoReader:
         try:
             shape = (self.batch_size, self.height, self.width, 3)
             if self._upload is None:
-                from . import runtime
+                from . import affinity, runtime
+                # this thread's memcpy into the pinned buffers, the buffers themselves (first touch) and the DMA out of them
+                # stay on the NUMA node the GPU hangs off
+                affinity.bind(runtime.device_index(self._device))
                 ctx = runtime.new_context(self._device)            # own HIP stream: uploads overlap the consumer's kernels
                 bufs = [ctx.pinned_array(shape) for _ in range(2)]
                 arrays = [b[0] for b in bufs]
