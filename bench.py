@@ -168,6 +168,9 @@ def main():
     ap.add_argument('--lane-embedders', action='store_true',
                     help='A/B: one embed thread + ArcFace model per lane (64 crops per launch) instead of one embed worker per '
                          'device that launches on the faces of several batches')
+    ap.add_argument('--embed-min-crops', type=int, default=256, help='embed worker: launch once this many faces are waiting ...')
+    ap.add_argument('--embed-max-crops', type=int, default=512, help='... on at most this many ...')
+    ap.add_argument('--embed-max-wait', type=float, default=0.020, help='... or this many seconds after the first of them arrived')
     ap.add_argument('--single-process', action='store_true',
                     help='--gpus N devices driven by ONE process through the facades\' device-list fan-out')
     ap.add_argument('--devices', default=None, help='with --single-process: comma-separated device ids (repeats allowed)')
@@ -470,7 +473,8 @@ def run(args):
         for p in pipes:
             p.load(precision)
         if streaming:
-            engine['sp'] = StreamPipeline([device_index], inflight=L, pick_faces=pick_faces, shared_embedder=not args.lane_embedders,
+            engine['sp'] = StreamPipeline([device_index], inflight=L, pick_faces=pick_faces, shared_embedder=not args.lane_embedders, embed_min_crops=args.embed_min_crops,
+                                          embed_max_crops=args.embed_max_crops, embed_max_wait=args.embed_max_wait,
                                           detection_kw=dict(short_side=416, state=sd_r, precision=precision),
                                           recognition_kw=dict(state=sd_a, precision=precision),
                                           estimation_kw=dict(short_side=184, state=sd_p, precision=precision))
@@ -573,7 +577,7 @@ def run(args):
                     '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or HEADLINE)
-    head = run_mode(primary, args.steps, extra_headline, min_seconds=0.0 if args.single_mode else args.sustain_seconds)
+    head = run_mode(primary, args.steps, extra_headline, min_seconds=args.sustain_seconds)
     elapsed, steps_timed, out, klass = head['elapsed'], head['steps'], head['out'], head['klass']
     others = {}
     if not args.single_mode:
@@ -647,7 +651,8 @@ def run(args):
                                 'ends when the last step is collected'
                                 % (L, L, 'an embed thread per lane consumes the detections of its batch' if args.lane_embedders else
                                    'ONE embed worker takes the detections of all lanes and launches ArcFace on the faces of several '
-                                   'batches at once (>= 192 crops or 10 ms; %.0f crops per launch measured)' % head.get('crops_per_embed_launch', 0)),
+                                   'batches at once (>= %d crops or %.0f ms; %.0f crops per launch measured)'
+                                   % (args.embed_min_crops, args.embed_max_wait * 1e3, head.get('crops_per_embed_launch', 0))),
             },
             'roofline': dict(conv_roofline(primary, klass['conv_igemm']),
                              # the same algorithmic FLOPs over the PIPELINED step (what `value` is made of): above the serial
@@ -867,7 +872,8 @@ def run_single_process(args):
         return [[{'landmarks': x['landmarks']} for x in d[:F]] + [{'landmarks': fallback_lm[k]} for k in range(len(d[:F]), F)]
                 for d in dets]
     L = max(1, args.inflight)
-    pipe = StreamPipeline(devices, inflight=L, pick_faces=pick, shared_embedder=not args.lane_embedders,
+    pipe = StreamPipeline(devices, inflight=L, pick_faces=pick, shared_embedder=not args.lane_embedders, embed_min_crops=args.embed_min_crops,
+                                          embed_max_crops=args.embed_max_crops, embed_max_wait=args.embed_max_wait,
                           detection_kw=dict(short_side=416, state=sd_r, precision=prec),
                           recognition_kw=dict(state=sd_a, precision=prec),
                           estimation_kw=dict(short_side=184, state=sd_p, precision=prec))

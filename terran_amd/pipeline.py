@@ -261,8 +261,8 @@ class StreamPipeline:
     """
 
     def __init__(self, devices, inflight=2, depth=2, pick_faces=all_faces, detection_kw=None, recognition_kw=None,
-                 estimation_kw=None, switch_interval=2e-4, shared_embedder=True, embed_min_crops=192, embed_max_crops=384,
-                 embed_max_wait=0.010):
+                 estimation_kw=None, switch_interval=2e-4, shared_embedder=True, embed_min_crops=256, embed_max_crops=512,
+                 embed_max_wait=0.020):
         """switch_interval: the lanes' threads spend their time inside GIL-free library calls; one that comes back must not
         wait a whole 5 ms interpreter time slice behind another thread's result handling before it can queue its next
         launches.  The interpreter-wide switch interval is lowered to this value while the pipeline lives (None: left alone)
