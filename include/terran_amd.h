@@ -37,8 +37,9 @@ extern "C" {
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
 #define TA_E_OVERFLOW (-4)  /* an addressing limit was hit (ta_openpose_run: more than 65535 peaks of ONE body part in one image) */
-#define TA_E_RANGE (-5)     /* f16x3 / f16 arithmetic modes only: an activation left the half-float range (|x| > 65504); no
-                             * numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
+#define TA_E_RANGE (-5)     /* f16x3 / f16 arithmetic modes only: an activation left the half-float range (stored |x| > 65504, inf
+                             * or NaN; tensors are stored times a pack-time power of two that puts the expected maximum near 2^10);
+                             * no numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
 
 #define TA_MODEL_RETINAFACE 1
 #define TA_MODEL_ARCFACE 2
@@ -110,6 +111,15 @@ int ta_model_forward_frames(ta_model* m, const ta_frames* frames);
 int ta_model_forward_crops(ta_model* m, const uint8_t* crops_nchw_bgr, int n);
 int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* w);
 int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst_nchw);
+
+/* f16x3 / f16 programs store every tensor times a power of two chosen at pack time (terran_amd/pack.py: tensor_scales);
+ * ta_model_read_tensor divides it out.  ta_model_tensor_scale reports the exponent.  ta_model_debug_amax (tools / tests: does
+ * the packer's expectation hold?): enable != 0 starts (or restarts, zeroed) the collection of the largest |x| every conv /
+ * dw+pw op STORES (in stored, i.e. scaled, units); with out != NULL the maxima collected so far are copied out first:
+ * out[2 i] = op i's output, out[2 i + 1] = the depthwise intermediate of a dw+pw op; capacity >= 2 x the number of ops
+ * (TA_E_CAPACITY otherwise).  enable == 2 only reads (the collection goes on), enable == 0 ends it. */
+int ta_model_tensor_scale(const ta_model* m, int tensor, int* scale_log2);
+int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity);
 
 /* ---- RetinaFace.call (retinaface/wrapper.py:133-238) ------------------------------------ */
 /* frames: (N,H,W,3) uint8 RGB at network resolution.  Per image: threshold (>=), sort by

@@ -124,6 +124,28 @@ __device__ __forceinline__ int ta_border_class(int y, int x, int Ho, int Wo) {
   return cy * 4 + cx;
 }
 
+// ---- range guard of the half-float programs -----------------------------------------------------------------------------------
+// Every epilogue of a program with half-float convs (ta_conv_launch::range_check) tracks the largest |x| it STORES -- whatever
+// the op's own arithmetic mode and the tensor's format: a float32 tensor written by an exact-f32 op may be split into half
+// floats in registers by its consumer.  The maximum is taken on BIT PATTERNS (sign cleared): for non-negative floats integer
+// order is float order, and inf / NaN sort above every finite value -- fmaxf would drop a NaN and let it through.
+#define TA_F16_MAX_BITS 0x477FE000u               /* 65504.0f */
+__device__ __forceinline__ unsigned ta_absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned ta_amax4(unsigned m, const f32x4& v) {
+  return max(max(m, max(ta_absbits(v[0]), ta_absbits(v[1]))), max(ta_absbits(v[2]), ta_absbits(v[3])));
+}
+// end of an epilogue: raise the flag; tools (ta_model_debug_amax) also collect the maximum itself per op
+__device__ __forceinline__ void ta_range_report(const ta_conv_launch& p, unsigned amax) {
+  if (amax > TA_F16_MAX_BITS) *p.range_flag = 1;
+  if (p.amax_slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
+    if ((threadIdx.x & 63) == 0 && amax) atomicMax(p.amax_slot, amax);
+  }
+}
+// ReLU that keeps a NaN a NaN (`v > 0 ? v : 0` turns it into 0 and hides it from the range guard)
+__device__ __forceinline__ float ta_relu(float v) { return v < 0.f ? 0.f : v; }
+
 // Fused epilogue shared by both kernels.  acc[a][b][r]: pixel = tile col (lane&31);
 // cout = 8*(r>>2) + 4*(lane>>5) + (r&3) within the 32x32 tile.
 template <int WM_TILES, int WN_TILES>
@@ -147,9 +169,12 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
       for (int j = 0; j < 4; ++j) slope[a][j] = *(const f32x4*)(p.prelu + co_base + a * 32 + 8 * j);
   }
   const int co_max = p.cout - 4;
-  const float us = p.w_unscale;
-  float amax = 0.f;                               // f16x3: largest |x| stored.  EVERY output of that mode is checked, float32 ones
-                                                  // too -- a conv that reads them splits them into half floats in registers
+  f32x4 us[WM_TILES][4];                          // per-channel power of two: weight-row exponent and activation scales (ta_op_desc.wus_off)
+#pragma unroll
+  for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) us[a][j] = *(const f32x4*)(p.wus + co_base + a * 32 + 8 * j);
+  unsigned amax = 0;                              // largest |x| stored, as a bit pattern (ta_range_report)
 #pragma unroll
   for (int b = 0; b < WN_TILES; ++b) {
     const int pix_raw = pix_tile0 + b * 32 + (lane & 31);
@@ -165,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, bias[a][j][e]);   // us == 1: acc + bias
+        for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us[a][j][e], bias[a][j][e]);   // us == 1: acc + bias
     if (p.bias9) {                                      // border pixels: the class's bias instead (see ta_border_class)
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
       if (cls != TA_INTERIOR) {
@@ -175,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
           for (int j = 0; j < 4; ++j) {
             const f32x4 b9 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co_base + a * 32 + 8 * j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us, b9[e]);
+            for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us[a][j][e], b9[e]);
           }
       }
     }
@@ -185,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] = v[a][j][e] > 0.f ? v[a][j][e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[a][j][e] = ta_relu(v[a][j][e]);
     } else if (p.act == TA_ACT_PRELU) {
 #pragma unroll
       for (int a = 0; a < WM_TILES; ++a)
@@ -210,7 +235,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] += r4[a][j][e];
+          for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(r4[a][j][e], p.res_scale, v[a][j][e]);   // res_scale == 1: v + r
     }
     float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
     if (pix_ok) {
@@ -221,8 +246,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
           const int co = co_base + a * 32 + 8 * j;
           if (co < p.cout) {
             ta_st4(o, p.out_ch + co, p.out_fmt, v[a][j]);
-            if (prec_half(p.prec))
-              amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[a][j][0]), fabsf(v[a][j][1]))), fmaxf(fabsf(v[a][j][2]), fabsf(v[a][j][3])));
+            if (p.range_check) amax = ta_amax4(amax, v[a][j]);
           }
         }
     }
@@ -247,13 +271,13 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
             for (int e = 0; e < 4; ++e) z[e] = v[a][j][e] * sc[a][j][e] + sh[a][j][e];
             if (co < p.cout) {
               ta_st4(o2, p.o2_ch + co, p.o2_fmt, z);
-              if (prec_half(p.prec)) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
+              if (p.range_check) amax = ta_amax4(amax, z);
             }
           }
       }
     }
   }
-  if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
+  ta_range_report(p, amax);
 }
 
 // ---- LDS-staged epilogue of the symmetric-wave kernels (conv_igemm, conv_igemm_pipe, conv_dwpw) ---------------------
@@ -833,6 +857,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
     src[j] = p.in + (size_t)img * p.in_img + (size_t)(y * p.dw_stride) * p.in_row + (size_t)(x * p.dw_stride) * p.in_pix + p.in_off0;
   }
 
+  unsigned dw_amax = 0;                            // largest depthwise value (bit pattern), split-half variant only
   auto produce = [&](int s, int stage) {
     float* base = lds + stage * STAGE;
 #pragma unroll
@@ -864,7 +889,9 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v[t][e], w9[t][e], acc[e]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+        for (int e = 0; e < 4; ++e) acc[e] = ta_relu(acc[e]);
+        // split-half 1x1: these rows are split into half floats in registers -- they are range-checked like a stored tensor
+        if constexpr (PREC != PREC_F32) dw_amax = ta_amax4(dw_amax, acc);
       }
       *(f32x4*)(base + (BN + row) * 32 + ((c4 ^ ((row >> 1) & 7)) * 4)) = acc;
     }
@@ -891,6 +918,14 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
     if (s + 1 < S) produce(s + 1, (s + 1) & 1);
     const float* st = lds + (s & 1) * STAGE;
     conv_slab_mma<WM_TILES, WN_TILES, PREC>(st, acc, a_row0, b_row0, fsw, fcb, lane);
+  }
+  if constexpr (PREC != PREC_F32) {
+    if (dw_amax > TA_F16_MAX_BITS) *p.range_flag = 1;
+    if (p.amax_mid_slot) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dw_amax = max(dw_amax, (unsigned)__shfl_xor((int)dw_amax, o));
+      if (lane == 0 && dw_amax) atomicMax(p.amax_mid_slot, dw_amax);
+    }
   }
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
@@ -1021,14 +1056,10 @@ __device__ __forceinline__ void ta_st8(float* pix, int ch, int fmt, const ta_f32
   *(uint4*)(q + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
 }
 
-// largest |x| among the n4 (1 or 2) stored 4-channel halves of v
-__device__ __forceinline__ float ta_absmax8(float m, const ta_f32x8& v, int n4) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v.a[e]));
-  if (n4 == 2) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v.b[e]));
-  }
+// largest |x| (bit pattern) among the n4 (1 or 2) stored 4-channel halves of v
+__device__ __forceinline__ unsigned ta_absmax8(unsigned m, const ta_f32x8& v, int n4) {
+  m = ta_amax4(m, v.a);
+  if (n4 == 2) m = ta_amax4(m, v.b);
   return m;
 }
 
@@ -1059,9 +1090,8 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   constexpr int RPI = NT / G;                      // pixel rows per pass of the workgroup
   const int k8 = tid % G, r0 = tid / G;
   const int co = ct0 + 8 * k8;
-  const float us = p.w_unscale;
-  float amax = 0.f;                                // f16x3: largest |x| stored (every output of that mode, see conv_epilogue)
-  const bool chk = prec_half(p.prec), chk2 = chk && p.out2;
+  unsigned amax = 0;                               // largest |x| stored, as a bit pattern (ta_range_report)
+  const bool chk = p.range_check, chk2 = chk && p.out2;
   if (p.k_split > 1) {                             // K-split: raw sums of this K range -> partial[ks][pixel][coutp]
     float* dst = p.partial + (size_t)ks * p.M * p.coutp + co;
     for (int row = r0; row < BM && pt0 + row < p.M; row += RPI) {
@@ -1075,6 +1105,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   const int n4 = p.cout - co >= 8 ? 2 : (p.cout - co >= 4 ? 1 : 0);    // valid 4-channel halves (cout % 4 == 0)
   if (n4 == 0) return;
   const f32x4 bias0 = *(const f32x4*)(p.bias + co), bias1 = *(const f32x4*)(p.bias + co + 4);   // padded to coutp
+  const f32x4 us0 = *(const f32x4*)(p.wus + co), us1 = *(const f32x4*)(p.wus + co + 4);          // per-channel power of two
   f32x4 sl0 = {0, 0, 0, 0}, sl1 = {0, 0, 0, 0}, sc0 = sl0, sc1 = sl0, sh0 = sl0, sh1 = sl0;
   if (p.act == TA_ACT_PRELU) {
     sl0 = *(const f32x4*)(p.prelu + co);
@@ -1100,11 +1131,11 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v.a[e] = __builtin_fmaf(v.a[e], us, bias0[e]);
-        v.b[e] = __builtin_fmaf(v.b[e], us, bias1[e]);
+        v.a[e] = __builtin_fmaf(v.a[e], us0[e], bias0[e]);
+        v.b[e] = __builtin_fmaf(v.b[e], us1[e], bias1[e]);
         if (p.act == TA_ACT_RELU) {
-          v.a[e] = v.a[e] > 0.f ? v.a[e] : 0.f;
-          v.b[e] = v.b[e] > 0.f ? v.b[e] : 0.f;
+          v.a[e] = ta_relu(v.a[e]);
+          v.b[e] = ta_relu(v.b[e]);
         }
       }
 #pragma unroll
@@ -1123,7 +1154,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
         if (chk) amax = ta_absmax8(amax, v, n4);
       }
     }
-    if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
+    ta_range_report(p, amax);
     return;
   }
   int pix = pt0 + r0;
@@ -1146,14 +1177,14 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v.a[e] = __builtin_fmaf(v.a[e], us, bb0[e]);
-      v.b[e] = __builtin_fmaf(v.b[e], us, bb1[e]);
+      v.a[e] = __builtin_fmaf(v.a[e], us0[e], bb0[e]);
+      v.b[e] = __builtin_fmaf(v.b[e], us1[e], bb1[e]);
     }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v.a[e] = v.a[e] > 0.f ? v.a[e] : 0.f;
-        v.b[e] = v.b[e] > 0.f ? v.b[e] : 0.f;
+        v.a[e] = ta_relu(v.a[e]);
+        v.b[e] = ta_relu(v.b[e]);
       }
     } else if (p.act == TA_ACT_PRELU) {
 #pragma unroll
@@ -1169,13 +1200,13 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
         const ta_f32x8 r = ta_ld8(rs, p.res_ch + co, p.res_fmt);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v.a[e] += r.a[e];
-          v.b[e] += r.b[e];
+          v.a[e] = __builtin_fmaf(r.a[e], p.res_scale, v.a[e]);     // res_scale == 1: v + r
+          v.b[e] = __builtin_fmaf(r.b[e], p.res_scale, v.b[e]);
         }
       } else {
         const f32x4 r = ta_ld4(rs, p.res_ch + co, p.res_fmt);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v.a[e] += r[e];
+        for (int e = 0; e < 4; ++e) v.a[e] = __builtin_fmaf(r[e], p.res_scale, v.a[e]);
       }
     }
     float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
@@ -1203,7 +1234,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       }
     }
   }
-  if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
+  ta_range_report(p, amax);
 }
 
 // ---- the same phase 2, specialised at compile time for the three epilogues that carry the bf16 workloads (launcher
@@ -1214,7 +1245,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
 // F16 (the format kind): 0 = TA_FMT_SPLIT (bf16 words), 1 = TA_FMT_SPLIT16 (half words), 2 = TA_FMT_F16 (plain half floats, one
 // 16-byte chunk per 8 channels); for 1 and 2 `amax` collects the largest |x| stored (range flag)
 template <int F16>
-__device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], float& amax) {
+__device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], unsigned& amax) {
   if constexpr (F16 == 2) {
     *(uint4*)q = make_uint4(ta_pack_half2(x[0], x[1]), ta_pack_half2(x[2], x[3]), ta_pack_half2(x[4], x[5]), ta_pack_half2(x[6], x[7]));
   } else {
@@ -1226,7 +1257,7 @@ __device__ __forceinline__ void ta_split_store8(char* q, const float (&x)[8], fl
   }
   if constexpr (F16 != 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));   // one v_max3_f32 per pair
+    for (int i = 0; i < 4; ++i) amax = max(amax, max(ta_absbits(x[2 * i]), ta_absbits(x[2 * i + 1])));   // bit patterns: a NaN cannot hide
   }
 }
 template <int BN, int BM, int NT, int ACT, bool RES, int F16, bool POOL = false, bool OUT2 = RES, bool B9 = false>
@@ -1238,9 +1269,11 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
   const int k8 = tid % G, r0 = tid / G;
   const int co = ct0 + 8 * k8;
   if (co >= p.cout) return;                        // cout % 8 == 0: a lane is inside or outside with all 8 channels
-  float bias[8], sl[8], sc[8], sh[8];
+  float bias[8], sl[8], sc[8], sh[8], us[8];
   *(f32x4*)bias = *(const f32x4*)(p.bias + co);
   *(f32x4*)(bias + 4) = *(const f32x4*)(p.bias + co + 4);
+  *(f32x4*)us = *(const f32x4*)(p.wus + co);
+  *(f32x4*)(us + 4) = *(const f32x4*)(p.wus + co + 4);
   if (ACT == TA_ACT_PRELU) {
     *(f32x4*)sl = *(const f32x4*)(p.prelu + co);
     *(f32x4*)(sl + 4) = *(const f32x4*)(p.prelu + co + 4);
@@ -1252,8 +1285,8 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     *(f32x4*)(sh + 4) = *(const f32x4*)(p.shift2 + co + 4);
   }
   auto chan = [](int ch) { return F16 == 2 ? (unsigned)(2 * ch) : ta_split_chan(ch); };
-  const float us = p.w_unscale;
-  float amax = 0.f;
+  const float rsc = p.res_scale;
+  unsigned amax = 0;
   char* const ob = (char*)p.out + chan(p.out_ch + co);
   const char* const rb = RES ? (const char*)p.res + chan(p.res_ch + co) : nullptr;
   char* const o2b = OUT2 ? (char*)p.out2 + chan(p.o2_ch + co) : nullptr;
@@ -1293,9 +1326,8 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (F16 != 0) v[e] = __builtin_fmaf(v[e], us, bb[e]);      // weights were packed times 2^wscale_log2
-      else v[e] += bb[e];
-      if (ACT == TA_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      v[e] = __builtin_fmaf(v[e], us[e], bb[e]);       // us = 2^(a_out - a_in - s[co]); all ones in the bf16 programs: v + bb
+      if (ACT == TA_ACT_RELU) v[e] = ta_relu(v[e]);
       if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
     }
     if (RES) {
@@ -1304,8 +1336,8 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
         float h0, h1, l0 = 0.f, l1 = 0.f;
         ta_unpack2<F16 != 0>(rh[i], h0, h1);
         if (F16 != 2) ta_unpack2<F16 != 0>(rl[i], l0, l1);
-        v[2 * i] += h0 + l0;
-        v[2 * i + 1] += h1 + l1;
+        v[2 * i] = __builtin_fmaf(h0 + l0, rsc, v[2 * i]);           // rsc == 1: v + r
+        v[2 * i + 1] = __builtin_fmaf(h1 + l1, rsc, v[2 * i + 1]);
       }
     }
     if (POOL) {
@@ -1341,9 +1373,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
       }
     }
   }
-  if constexpr (F16 != 0) {
-    if (!(amax <= TA_F16_MAX)) *p.range_flag = 1;
-  }
+  if constexpr (F16 != 0) ta_range_report(p, amax);
 }
 // picks the lean drain when the launch qualifies; false = run the generic one
 template <int BN, int BM, int NT, int F16>
@@ -1659,6 +1689,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     const int rem = pix - img * HoWo;
     const int y = rem / p.Wo, x = rem - y * p.Wo;
     f32x4 v = *(const f32x4*)(p.bias + co);
+    const f32x4 us = *(const f32x4*)(p.wus + co);
     if (p.bias9) {
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
       if (cls != TA_INTERIOR) v = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
@@ -1666,11 +1697,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     for (int k = 0; k < p.k_split; ++k) {
       const f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * p.M + pix) * p.coutp + co);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], p.w_unscale, v[e]);      // w_unscale == 1: v + t
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], us[e], v[e]);      // us == 1: v + t
     }
     if (p.act == TA_ACT_RELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = ta_relu(v[e]);
     } else if (p.act == TA_ACT_PRELU) {
       const f32x4 sl = *(const f32x4*)(p.prelu + co);
 #pragma unroll
@@ -1680,20 +1711,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
       const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
       const f32x4 r = ta_ld4(p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0, p.res_ch + co, p.res_fmt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += r[e];
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(r[e], p.res_scale, v[e]);
     }
     ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, p.out_ch + co,
            p.out_fmt, v);
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    unsigned amax = ta_amax4(0u, v);
     if (p.out2) {
       const f32x4 sc = *(const f32x4*)(p.scale2 + co), sh = *(const f32x4*)(p.shift2 + co);
       f32x4 z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) z[e] = v[e] * sc[e] + sh[e];
       ta_st4(p.out2 + (size_t)img * p.o2_img + (size_t)y * p.o2_row + (size_t)x * p.o2_pix + p.o2_off0, p.o2_ch + co, p.o2_fmt, z);
-      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
+      amax = ta_amax4(amax, z);
     }
-    if (prec_half(p.prec) && !(amax <= TA_F16_MAX)) *p.range_flag = 1;
+    if (p.range_check) ta_range_report(p, amax);
   }
 }
 
@@ -1808,7 +1839,8 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
 int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p_in.M <= 0) return TA_OK;
   ta_conv_launch p = p_in;
-  if (!(p.w_unscale > 0.f)) p.w_unscale = 1.f;
+  if (!p.wus) return ta_fail(ctx, TA_E_INVALID, "dw+pw: no un-scale vector");
+  if (!(p.res_scale > 0.f)) p.res_scale = 1.f;
   p.range_flag = ctx->range_flag;
   if ((p.prec != PREC_F32 && p.prec != PREC_F16X3) || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w ||
       !p.dw_bias || p.n_slabs * 32 < p.dw_c)
@@ -1897,7 +1929,9 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p.in_fmt != TA_FMT_F32 && p.in_fmt != ta_split_fmt_of(p.prec))
     return ta_fail(ctx, TA_E_INVALID, "conv: input tensor format %d does not belong to precision mode %d", p.in_fmt, p.prec);
   p.range_flag = ctx->range_flag;
-  if (!(p.w_unscale > 0.f)) p.w_unscale = 1.f;
+  if (!p.wus) return ta_fail(ctx, TA_E_INVALID, "conv: no un-scale vector");
+  if (!(p.res_scale > 0.f)) p.res_scale = 1.f;
+  if (prec_half(p.prec)) p.range_check = 1;
   int v = p.variant;
   if (v != TA_CV_AUTO) {
     if (!variant_eligible(v, p))

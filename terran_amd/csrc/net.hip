@@ -112,6 +112,7 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
     ts[i].c = m->tdesc[i].channels;
     ts[i].halo = m->tdesc[i].halo;
     ts[i].fmt = m->tdesc[i].fmt;
+    ts[i].scale_log2 = m->tdesc[i].scale_log2;
     ts[i].n = n;
   }
   const int in_id = m->hdr.input_tensor;
@@ -419,7 +420,10 @@ int ta_model_run_ops(ta_model* m) {
         }
         p.variant = op.variant & 255;
         if ((op.variant >> 16) & 1) p.bias9 = wptr(m, op.scale2_off);
-        p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
+        p.wus = wptr(m, op.wus_off);
+        p.res_scale = op.res >= 0 ? ldexpf(1.0f, to.scale_log2 - m->tensors[op.res].scale_log2) : 1.0f;
+        p.range_check = m->has_half_ops ? 1 : 0;
+        p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
           p.pool = 1;
@@ -456,7 +460,11 @@ int ta_model_run_ops(ta_model* m) {
         p.act = op.act;
         p.stride = 1;
         p.prec = op.prec;
-        p.w_unscale = ldexpf(1.0f, -op.wscale_log2);
+        p.wus = wptr(m, op.wus_off);
+        p.res_scale = 1.0f;
+        p.range_check = m->has_half_ops ? 1 : 0;
+        p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
+        p.amax_mid_slot = m->amax_dev ? m->amax_dev + 2 * oi + 1 : nullptr;
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;
         p.in_pix = ti.c;
@@ -518,7 +526,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 7) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 8) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version (this library reads version 8)");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -541,7 +549,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
     if (op.type == TA_OP_CONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
-            op.stride <= 0 || op.wscale_log2 < -60 || op.wscale_log2 > 60 || (op.prec != 3 && op.prec != 4 && op.wscale_log2 != 0) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            op.stride <= 0 || op.wus_off < 0 || bad_w(op.wus_off, (size_t)op.coutp * 4) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||
@@ -551,7 +559,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
       bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
     } else if (op.type == TA_OP_DWPW) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.scale2_off < 0 || op.shift2_off < 0 || op.cin % 4 || op.cout % 4 ||
-            (op.prec != 0 && op.prec != 3) || (op.prec != 3 && op.wscale_log2 != 0) ||
+            (op.prec != 0 && op.prec != 3) || op.wus_off < 0 || bad_w(op.wus_off, (size_t)op.coutp * 4) ||
             op.coutp % 32 || op.n_slabs <= 0 || op.n_slabs * 32 < op.cin || (op.stride != 1 && op.stride != 2) ||
             bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) || bad_w(op.bias_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.cin * 36) || bad_w(op.shift2_off, (size_t)op.cin * 4);
@@ -562,6 +570,28 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     if (bad) {
       delete m;
       return ta_fail(ctx, TA_E_INVALID, "model blob: malformed op");
+    }
+  }
+  {  // activation scales: the host and the post-processing kernels read the input and the outputs as they are; tensors that share
+     // memory or are copied raw must agree; a shortcut may differ from the sum it joins by a power of two (ta_conv_launch::res_scale)
+    bool bad = false;
+    auto sc = [&](int t) { return m->tdesc[t].scale_log2; };
+    for (int t = 0; t < h.n_tensors; ++t) {
+      if (sc(t) < -64 || sc(t) > 64) bad = true;
+      const int a = m->tdesc[t].alias_of;
+      if (a >= 0 && (a >= h.n_tensors || sc(a) != sc(t))) bad = true;
+    }
+    if (sc(h.input_tensor) != 0) bad = true;
+    for (int i = 0; i < h.n_outputs; ++i)             // (an output may carry a scale: its reader applies it -- OpenPose's maps live in
+      if (h.outputs[i] < 0 || h.outputs[i] >= h.n_tensors) bad = true;   //  the ping-pong stage tensor -- or insists on 0)
+    for (auto& op : m->ops) {
+      if ((op.type == TA_OP_MAXPOOL || op.type == TA_OP_COPYCH) && sc(op.in) != sc(op.out)) bad = true;
+      if (op.type == TA_OP_DWCONV && (sc(op.in) != 0 || sc(op.out) != 0)) bad = true;
+      if ((op.type == TA_OP_CONV || op.type == TA_OP_DWPW) && (op.prec == 3 || op.prec == 4)) m->has_half_ops = true;
+    }
+    if (bad) {
+      delete m;
+      return ta_fail(ctx, TA_E_INVALID, "model blob: inconsistent activation scales");
     }
   }
   {  // lanes (variant bits 17..18): a branch may read what earlier main-stream ops wrote and its own tensors; nothing outside
@@ -608,11 +638,40 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   return TA_OK;
 }
 
+int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity) {
+  ta_enter(m ? m->ctx : nullptr);
+  if (!m) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  const size_t n = 2 * m->ops.size();
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out) {
+    if (!m->amax_dev) return ta_fail(ctx, TA_E_INVALID, "debug_amax: not enabled");
+    if ((size_t)capacity < n) return ta_fail(ctx, TA_E_CAPACITY, "debug_amax: %zu floats needed", n);
+    TA_HIP(ctx, hipMemcpy(out, m->amax_dev, n * sizeof(float), hipMemcpyDeviceToHost));   // bit patterns of |x| ARE the floats
+  }
+  if (enable == 2) return TA_OK;                 // read only: the collection goes on
+  if (enable) {
+    if (!m->amax_dev) TA_HIP(ctx, hipMalloc((void**)&m->amax_dev, n * sizeof(unsigned)));
+    TA_HIP(ctx, hipMemset(m->amax_dev, 0, n * sizeof(unsigned)));
+  } else if (m->amax_dev) {
+    (void)hipFree(m->amax_dev);
+    m->amax_dev = nullptr;
+  }
+  return TA_OK;
+}
+
+int ta_model_tensor_scale(const ta_model* m, int tensor, int* scale_log2) {
+  if (!m || !scale_log2 || tensor < 0 || tensor >= (int)m->tdesc.size()) return TA_E_INVALID;
+  *scale_log2 = m->tdesc[tensor].scale_log2;
+  return TA_OK;
+}
+
 void ta_model_free(ta_model* m) {
   ta_enter(m ? m->ctx : nullptr);
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
   free_plans(m);
+  if (m->amax_dev) (void)hipFree(m->amax_dev);
   if (m->weights_dev) (void)hipFree(m->weights_dev);
   delete m;
 }
@@ -667,6 +726,7 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
   ta_ctx* ctx = m->ctx;
   const ta_tensor& t = m->tensors[tensor];
   if (!t.dev || ch_off < 0 || ch <= 0 || ch_off + ch > t.c) return ta_fail(ctx, TA_E_INVALID, "read_tensor: bad slice");
+  const float unscale = ldexpf(1.0f, -t.scale_log2);       // the tensor is stored times 2^scale_log2
   std::vector<float> host((size_t)m->run_n * t.hp() * t.wp() * t.c);
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TA_HIP(ctx, hipMemcpy(host.data(), t.dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -701,7 +761,7 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
           } else {
             v = host[t.off(i, y, x) + cc];
           }
-          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = v;
+          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = v * unscale;
         }
   return TA_OK;
 }

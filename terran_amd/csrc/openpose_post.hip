@@ -41,6 +41,7 @@ struct op_maps {
   int paf_ch, hm_ch;      // first PAF / heat-map channel
   int fmt;                // TA_FMT_F32 or TA_FMT_SPLIT (act_format.h)
   int h, w;
+  float unscale;          // the maps are stored times a power of two (ta_tensor::scale_log2): every read multiplies it out (exact)
 };
 
 // ---- 1. bicubic x8 ------------------------------------------------------------------------------
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, fl
     int col = q0 - 2 + lc;
     col = col < 0 ? 0 : (col > m.w - 1 ? m.w - 1 : col);
     const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
-    bc_sm[(sr * 57 + c) * WP + lc] = ta_ld1(src + (size_t)row * m.row + (size_t)col * m.pix, ch, m.fmt);
+    bc_sm[(sr * 57 + c) * WP + lc] = ta_ld1(src + (size_t)row * m.row + (size_t)col * m.pix, ch, m.fmt) * m.unscale;
   }
   __syncthreads();
   for (int task = threadIdx.x; task < 57 * 8 * tw; task += 256) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void op_planar_kernel(const op_maps m, int img
     const int cell = (int)(i % cells);
     const int c = (int)((i / cells) % 57), img = (int)(i / (cells * 57));
     const float* src = m.base + (size_t)(img_base + img) * m.img + m.off0 + (size_t)(cell / m.w) * m.row + (size_t)(cell % m.w) * m.pix;
-    out[i] = ta_ld1(src, c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38), m.fmt);
+    out[i] = ta_ld1(src, c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38), m.fmt) * m.unscale;
   }
 }
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
     wph = (float4*)(psm + (((size_t)h * wd * 4 + 15) & ~(size_t)15));   // 8
     cand = (unsigned long long*)(wph + 8);                           // OP_MAXP
     const float* src = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
-    for (int i = tid; i < h * wd; i += PK_T) smw[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt);
+    for (int i = tid; i < h * wd; i += PK_T) smw[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt) * w.m.unscale;
     sm = smw;
   }
   if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
@@ -362,8 +363,8 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
     const float* srcm = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
     for (int i = tid; i < mh * mw; i += 256) {
       const float* px = srcm + (size_t)(i / mw) * w.m.row + (size_t)(i % mw) * w.m.pix;
-      sx[i] = ta_ld1(px, w.m.paf_ch + chx, w.m.fmt);
-      sy[i] = ta_ld1(px, w.m.paf_ch + chy, w.m.fmt);
+      sx[i] = ta_ld1(px, w.m.paf_ch + chx, w.m.fmt) * w.m.unscale;
+      sy[i] = ta_ld1(px, w.m.paf_ch + chy, w.m.fmt) * w.m.unscale;
     }
     smx = sx;
     smy = sy;
@@ -1008,11 +1009,10 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
   mp.fmt = X.fmt;
   mp.h = X.h;
   mp.w = X.w;
+  mp.unscale = ldexpf(1.0f, -X.scale_log2);
   TA_TRY(ta_range_enqueue(ctx));                 // behind the network, ahead of the grouping's syncs
   const int rc = op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required);
-  if (rc != TA_OK && rc != TA_E_CAPACITY) return rc;
-  const int rr = ta_range_check(ctx);            // f16x3: TA_E_RANGE when an activation left the half-float range
-  return rr != TA_OK ? rr : rc;
+  return ta_range_finish(ctx, rc);               // f16x3: TA_E_RANGE when an activation left the half-float range
 }
 
 int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int n, int h, int w, double scale,
@@ -1039,6 +1039,7 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
   mp.fmt = TA_FMT_F32;
   mp.h = h;
   mp.w = w;
+  mp.unscale = 1.0f;
   const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(dev);
@@ -1125,6 +1126,7 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
     mp.fmt = TA_FMT_F32;
     mp.h = h;
     mp.w = w;
+    mp.unscale = 1.0f;
     std::vector<float> up((size_t)n * 57 * 64 * h * w);
     const int rc = op_upsample_dev(ctx, mp, n, up.data());
     (void)hipStreamSynchronize(ctx->stream);

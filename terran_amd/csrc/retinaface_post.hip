@@ -11,6 +11,7 @@
 #include <string.h>
 #include <vector>
 
+#include "act_format.h"
 #include "ta_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -491,12 +492,13 @@ int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, flo
   TA_TRY(ta_model_forward_frames(m, frames));
   TA_TRY(ta_range_enqueue(ctx));                 // behind the network, ahead of the post-processing's syncs
   ta_tensor heads[3];
-  for (int l = 0; l < 3; ++l) heads[l] = m->tensors[m->hdr.outputs[l]];
+  for (int l = 0; l < 3; ++l) {
+    heads[l] = m->tensors[m->hdr.outputs[l]];
+    if (heads[l].scale_log2 != 0 || heads[l].fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "retinaface_run: the head tensors must be plain float32");
+  }
   const int rc = rf_postprocess_dev(ctx, heads, frames->n, frames->h, frames->w, 0, score_thr, nms_thr, capacity, counts, boxes,
                                     landmarks, scores, required);
-  if (rc != TA_OK && rc != TA_E_CAPACITY) return rc;
-  const int rr = ta_range_check(ctx);            // f16x3 layers: TA_E_RANGE when an activation left the half-float range
-  return rr != TA_OK ? rr : rc;
+  return ta_range_finish(ctx, rc);               // f16x3 layers: TA_E_RANGE when an activation left the half-float range
 }
 
 int ta_retinaface_postprocess(ta_ctx* ctx, const float* const heads[9], int n, int h, int w, float score_thr,

@@ -58,6 +58,15 @@ int ta_range_check(ta_ctx* ctx) {
   return ta_fail(ctx, TA_E_RANGE, "f16x3: an activation exceeded the half-float range (|x| > 65504); run this input in the f32 or bf16x3 mode");
 }
 
+// End of a task entry point whose post-processing returned `rc`: garbage maps of an overflowed network can make the grouping /
+// selection fail in their own ways (TA_E_OVERFLOW with > 65535 "peaks", ...); the caller must then hear TA_E_RANGE -- the error it
+// can act on (re-run on the exact-f32 twin) -- and the flag must not survive into the next, unrelated call.
+int ta_range_finish(ta_ctx* ctx, int rc) {
+  if (rc != TA_OK && rc != TA_E_CAPACITY) (void)hipStreamSynchronize(ctx->stream);    // error paths may have returned before their sync
+  const int rr = ta_range_check(ctx);
+  return rr != TA_OK ? rr : rc;
+}
+
 // ---- profiling ---------------------------------------------------------------------------------
 static hipEvent_t get_event(ta_ctx* ctx) {
   if (!ctx->event_pool.empty()) {

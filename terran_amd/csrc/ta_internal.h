@@ -46,6 +46,10 @@ struct ta_tensor_desc {
   int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0);
                       // -2: shape only, never materialised (the float input of a program whose first op reads the frames)
   int32_t fmt;        // TA_FMT_F32 / TA_FMT_SPLIT (act_format.h)
+  int32_t scale_log2; // the tensor is STORED times 2^scale_log2 (f16x3 / f16 programs: keeps the half-float words normal and
+                      // away from 65504; chosen by the packer from the expected magnitude, terran_amd/pack.py tensor_scales).
+                      // Producers and consumers have the factor folded into their per-channel epilogue vectors; debug taps
+                      // (ta_model_read_tensor) divide it out.  0 for the input and for every tensor the host / post-processing reads
 };
 
 struct ta_op_desc {
@@ -67,13 +71,17 @@ struct ta_op_desc {
                                       // second output): a per-channel affine of the INPUT is folded into the weights;
                                       // bits 17..18: lane -- 1 / 2 = the op runs on side stream 1 / 2 (ta_model_run_ops)
   int32_t pool;                       // 1: a 2x2 / 2 max-pool (floor) is fused into the epilogue; `out` has the pooled size
-  int32_t wscale_log2;                // f16x3: the packed weights are W * 2^wscale_log2 (their lo halves stay normal half floats);
-                                      // the epilogue multiplies the sums by 2^-wscale_log2 (exact).  0 in the other modes
+  int32_t wscale_log2;                // reserved (0): blob versions <= 7 kept one weight exponent per layer here
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
+  int64_t wus_off;                    // conv / dw+pw: [coutp] floats, the power of two the raw sums of output channel co are multiplied
+                                      // with before the bias is added: 2^(a_out - a_in - s[co]) -- s[co] the exponent row co of the packed
+                                      // half-float weights carries (their lo halves stay normal), a_in / a_out the activation scales of
+                                      // the tensors read / written; bias, border-class biases and the second output's affine are packed
+                                      // times 2^a_out already.  All ones outside the f16x3 / f16 programs
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
 
-static_assert(sizeof(ta_blob_header) == 128 && sizeof(ta_tensor_desc) == 16 && sizeof(ta_op_desc) == 144,
+static_assert(sizeof(ta_blob_header) == 128 && sizeof(ta_tensor_desc) == 20 && sizeof(ta_op_desc) == 152,
               "blob layout is shared with terran_amd/pack.py (HEADER_DT / TENSOR_DT / OP_DT)");
 
 // ---------------------------------------------------------------------------------------------
@@ -154,6 +162,7 @@ struct ta_ctx {
 void ta_pose_free_big(ta_ctx* ctx);  // frees pose_dbg.over
 int ta_range_enqueue(ta_ctx* ctx);   // async copy of the flag on the context's stream (before the call's final sync)
 int ta_range_check(ta_ctx* ctx);     // after that sync: TA_OK, or TA_E_RANGE (and the flag is cleared for the next call)
+int ta_range_finish(ta_ctx* ctx, int rc);   // end of a task entry point: TA_E_RANGE takes precedence over the post-processing's own result
 
 // Conv kernel variants (ta_debug_conv_variant / ta_debug_conv_counts; include/terran_amd.h lists them)
 enum {
@@ -224,6 +233,7 @@ struct ta_frames {
 struct ta_tensor {
   float* dev = nullptr;   // base of the padded allocation
   int n = 0, h = 0, w = 0, c = 0, halo = 0, fmt = 0;
+  int scale_log2 = 0;     // stored values = true values * 2^scale_log2 (ta_tensor_desc)
   bool owns = true;
   int hp() const { return h + 2 * halo; }
   int wp() const { return w + 2 * halo; }
@@ -261,6 +271,7 @@ struct ta_conv_launch {
   const float* dw_w;                           // [9][dw_c]
   const float* dw_bias;                        // [dw_c]
   int dw_c, dw_stride;
+  unsigned* amax_mid_slot;                     // tools: the same for the depthwise intermediate of a dw+pw block
   // pool = 1 (split-role kernel only): tile pixels are ordered quad by quad -- pixel t of the launch is position
   // (t >> 1 & 1, t & 1) of 2x2 window t >> 2, windows in raster order over the POOLED map (Ho x Wo here are the pooled
   // sizes, M = 4 N Ho Wo) -- and the epilogue stores the max of every window instead of the four pixels
@@ -274,8 +285,12 @@ struct ta_conv_launch {
                                                //             2 = no DMA at all after the ring is full (WRONG results)
   const float* bias9;                          // border-class biases [16][coutp] of a conv with a folded input affine (nullptr: none)
   int late_b;                                  // tools only (TA_CONV_LATE_B): slab 0's pixel-row DMAs after ALL addresses are computed
-  float w_unscale;                             // sums are multiplied by this before the bias (2^-wscale_log2; 1 outside f16x3)
-  int* range_flag;                             // set to 1 by an epilogue that writes |x| > 65504 into a TA_FMT_SPLIT16 tensor
+  const float* wus;                            // [coutp]: the sums of channel co are multiplied by wus[co] before the bias (ta_op_desc.wus_off)
+  float res_scale;                             // the shortcut is added times this power of two (2^(a_out - a_res); 1 when the scales agree)
+  int range_check;                             // 1: the program has half-float convs -- EVERY store of EVERY op is range-checked (a float32
+                                               // tensor written by an exact-f32 op may be split into half floats by its consumer)
+  int* range_flag;                             // set to 1 by an epilogue that stores |x| > 65504, inf or NaN while range_check is on
+  unsigned* amax_slot;                         // tools (ta_model_debug_amax): atomicMax of the bit pattern of the largest |x| stored
 };
 
 // the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
@@ -340,6 +355,9 @@ struct ta_model {
   std::vector<ta_tensor_desc> tdesc;
   std::vector<ta_op_desc> ops;
   char* weights_dev = nullptr;
+  bool has_half_ops = false;                    // any conv / dw+pw op with prec 3 / 4: every store is range-checked (ta_conv_launch::range_check)
+  float* ones_dev = nullptr;                    // [max coutp] of 1.0f: the un-scale vector of ops packed without one
+  unsigned* amax_dev = nullptr;                 // tools (ta_model_debug_amax): [2 * n_ops] largest |x| bit patterns (output, dw intermediate)
   std::vector<char> weights_host_small;         // host copy of the few weights that travel as kernel arguments (TA_OP_RFSTEM)
   // small LRU of plans (lists of differently-sized images alternate between a few shapes); `tensors`,
   // `ktab_dev`, `ktab_off` mirror the active plan

@@ -56,6 +56,8 @@ SIGNATURES = {
     'ta_model_forward_frames': (c_int, [c_void_p, c_void_p]),
     'ta_model_forward_crops': (c_int, [c_void_p, c_void_p, c_int]),
     'ta_model_tensor_shape': (c_int, [c_void_p, c_int, P(c_int), P(c_int), P(c_int), P(c_int)]),
+    'ta_model_tensor_scale': (c_int, [c_void_p, c_int, P(c_int)]),
+    'ta_model_debug_amax': (c_int, [c_void_p, c_int, c_void_p, c_int]),
     'ta_model_read_tensor': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'ta_retinaface_run': (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, P(C.c_int32)]),
@@ -354,6 +356,33 @@ class Model:
         out = np.empty((n.value, ch, h.value, w.value), np.float32)
         self.ctx.check(self.ctx.lib.ta_model_read_tensor(self.h, tid, off, ch, ptr(out)))
         return out
+
+    def read_tensor(self, tid, ch_off=0, ch=None):
+        """Debug tap by tensor id (true values: the activation scale is divided out)."""
+        n, c, h, w = c_int(), c_int(), c_int(), c_int()
+        self.ctx.check(self.ctx.lib.ta_model_tensor_shape(self.h, tid, C.byref(n), C.byref(c), C.byref(h), C.byref(w)))
+        ch = c.value - ch_off if ch is None else ch
+        out = np.empty((n.value, ch, h.value, w.value), np.float32)
+        self.ctx.check(self.ctx.lib.ta_model_read_tensor(self.h, tid, ch_off, ch, ptr(out)))
+        return out
+
+    def tensor_scale(self, tid):
+        v = c_int()
+        self.ctx.check(self.ctx.lib.ta_model_tensor_scale(self.h, tid, C.byref(v)))
+        return v.value
+
+    def amax_collect(self, on=True):
+        """Start (zeroed) / stop collecting the largest |x| every conv / dw+pw op stores (ta_model_debug_amax)."""
+        self.ctx.check(self.ctx.lib.ta_model_debug_amax(self.h, int(bool(on)), None, 0))
+
+    def amax_read(self, n_ops):
+        """-> (n_ops, 2) float32 in STORED units: [:, 0] op outputs, [:, 1] depthwise intermediates of dw+pw ops; the
+        collection goes on (not zeroed)."""
+        out = np.zeros(2 * n_ops, np.float32)
+        n = c_int()
+        # read without restarting: enable = 1 would zero the slots, so read first through a second call
+        self.ctx.check(self.ctx.lib.ta_model_debug_amax(self.h, 2, ptr(out), out.size))
+        return out.reshape(n_ops, 2)
 
     def free(self):
         if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):

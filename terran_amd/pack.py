@@ -30,14 +30,36 @@ HEADER_DT = np.dtype({
     'offsets': [0, 4, 8, 12, 16, 20, 24, 28, 96, 104, 112, 120],
     'itemsize': 128,
 })
-TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4')])
+TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4'), ('scale_log2', '<i4')])
 FMT_F32, FMT_SPLIT, FMT_SPLIT16, FMT_F16 = 0, 1, 2, 3
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
            'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'wscale_log2']
-_OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off']
+_OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off', 'wus_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
-assert OP_DT.itemsize == 144 and TENSOR_DT.itemsize == 16
-BLOB_VERSION = 7            # 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+assert OP_DT.itemsize == 152 and TENSOR_DT.itemsize == 20
+BLOB_VERSION = 8            # 8: per-tensor activation scales (ta_tensor_desc.scale_log2) and per-output-channel un-scale vectors (ta_op_desc.wus_off) replace the per-layer wscale_log2; 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+
+
+# every environment switch a packer reads: a program packed with one of them set must never be served to a default run
+# (runtime.packed_program bypasses the on-disk repack cache then, and keys its in-process memo on them)
+PACK_SWITCHES = ('TERRAN_AMD_NO_FUSED_POOL', 'TERRAN_AMD_NO_GROUPED', 'TERRAN_AMD_NO_MERGED_OUTPUTS', 'TERRAN_AMD_ARCFACE_SECOND_OUTPUT',
+                 'TERRAN_AMD_NO_STAGE4_KSPLIT', 'TERRAN_AMD_DETECTOR_F32', 'TERRAN_AMD_DETECTOR_BASE_F32', 'TERRAN_AMD_NO_FUSED_DETECTOR',
+                 'TERRAN_AMD_NO_DETECTOR_LANES', 'TERRAN_AMD_NO_ACT_SCALES')
+
+
+def active_switches():
+    return tuple((k, os.environ[k]) for k in PACK_SWITCHES if os.environ.get(k))
+
+
+def source_tag():
+    """Short hash of the packer's own sources: a repack cache written by another version of pack.py / arch.py is not read."""
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in ('pack.py', 'arch.py'):
+        with open(os.path.join(here, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:10]
 
 
 PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3, 'f16': 4}
@@ -67,21 +89,71 @@ def split_bf16_rows(packed):
     return np.ascontiguousarray(rows).view(np.float32)      # (..., 32)
 
 
-def split_f16_rows(packed):
-    """[slab][cout][32] float32 -> ([hi x32 | lo x32] IEEE half rows viewed as float32, wscale_log2).
+def row_exponents(packed):
+    """[slab][cout][32] float32 -> per-output-channel exponents s[cout]: max |W[co, :]| 2^s[co] lies in [2^13, 2^14)
+    (0 for an all-zero row)."""
+    m = np.abs(np.asarray(packed, np.float32)).max(axis=(0, 2)).astype(np.float64)
+    ok = np.isfinite(m) & (m > 0)
+    s = np.zeros(m.shape, np.int64)
+    s[ok] = np.clip(13 - np.floor(np.log2(m[ok])), -60, 60).astype(np.int64)
+    return s
 
-    Half floats carry 11 significant bits down to 2^-14 only; a lo half below that loses bits.  The whole layer is
-    therefore packed times 2^s, s chosen so that max |W| 2^s lies in [2^13, 2^14): every weight within 2^-16 of the
-    largest keeps a normal lo half (22 significant bits in hi + lo), and nothing gets near 65504.  The conv epilogue
-    multiplies the sums by 2^-s, which is exact."""
+
+def split_f16_rows(packed, exps=None):
+    """[slab][cout][32] float32 -> ([hi x32 | lo x32] IEEE half rows viewed as float32, exponents s[cout]).
+
+    Half floats carry 11 significant bits down to 2^-14 only; a lo half below that loses bits.  Every OUTPUT CHANNEL's
+    row is therefore packed times 2^s[co], s[co] chosen so that max |W[co, :]| 2^s[co] lies in [2^13, 2^14): every weight
+    within 2^-16 of its row's largest keeps a normal lo half (22 significant bits in hi + lo), nothing gets near 65504,
+    and a channel whose weights are all small (a BatchNorm with a small gamma / sigma folded in) keeps its bits instead of
+    inheriting the scale of the layer's largest channel.  The conv epilogue multiplies the sums by 2^-s[co] (folded into
+    its per-channel un-scale vector, Program.blob), which is exact."""
     packed = np.ascontiguousarray(packed, dtype=np.float32)
-    m = float(np.abs(packed).max())
-    s = 0 if m == 0.0 or not np.isfinite(m) else int(np.clip(13 - np.floor(np.log2(m)), -40, 40))
-    scaled = np.ldexp(packed, s).astype(np.float32)               # exact (power of two)
+    s = row_exponents(packed) if exps is None else np.asarray(exps, np.int64)
+    scaled = np.ldexp(packed, s[None, :, None].astype(np.int32)).astype(np.float32)               # exact (powers of two)
     hi = scaled.astype(np.float16)
     lo = (scaled - hi.astype(np.float32)).astype(np.float16)
     rows = np.concatenate([hi.view(np.uint16), lo.view(np.uint16)], axis=-1)
     return np.ascontiguousarray(rows).view(np.float32), s
+
+
+# ---- moment propagation (plan-time activation scales) -------------------------------------------------------------------
+# The half-float formats of the f16x3 / f16 modes keep all their bits for |x| in [2^-3, 65504] only (TA_FMT_SPLIT16:
+# the lo half goes subnormal below; TA_FMT_F16: 2^-14).  Every tensor of a program with half-float convs is therefore
+# STORED times a power of two 2^a chosen at pack time so that its largest expected |x| 2^a lands near 2^10 -- 64 x of
+# headroom to the end of the range, 13 binades of full precision below.  Consumers fold 2^-a into their per-channel
+# un-scale vector, producers fold 2^a into bias / un-scale (ReLU and PReLU are positively homogeneous), so the kernels do
+# no extra work.  The expectation comes from propagating per-channel (mean, variance) through the folded weights:
+# Gaussian moments through ReLU / PReLU, independent channels, half-correlated filter taps.  It only has to be right to
+# within a few binades: a tensor that still overflows raises the range flag (TA_E_RANGE -> the wrappers' exact-f32 re-run).
+_SQRT2, _SQRT2PI = np.sqrt(2.0), np.sqrt(2.0 * np.pi)
+_TAP_CORR = 0.5          # share of the variance that adds coherently over the taps of a k x k filter (smooth images)
+_ACT_TARGET_LOG2 = 10    # estimated max |x| 2^a in (2^9, 2^10]
+_ACT_SIGMAS = 6.0
+
+
+def _erf(x):
+    from math import erf
+    return np.vectorize(erf, otypes=[np.float64])(x)
+
+
+def act_moments(mu, var, act, slope=None):
+    """(mean, variance) of relu(z) / prelu(z, slope) for z ~ N(mu, var), element-wise."""
+    if act == ACT_NONE:
+        return mu, var
+    mu, var = np.asarray(mu, np.float64), np.maximum(np.asarray(var, np.float64), 1e-60)
+    sd = np.sqrt(var)
+    t = mu / sd
+    Phi = 0.5 * (1.0 + _erf(t / _SQRT2))
+    phi = np.exp(-0.5 * t * t) / _SQRT2PI
+    m_pos = mu * Phi + sd * phi
+    s_pos = (mu * mu + var) * Phi + mu * sd * phi
+    m_neg = -mu * (1.0 - Phi) + sd * phi
+    s_neg = (mu * mu + var) * (1.0 - Phi) - mu * sd * phi
+    a = np.zeros_like(mu) if (act == ACT_RELU or slope is None) else np.asarray(slope, np.float64)
+    m = m_pos - a * m_neg
+    s2 = s_pos + a * a * s_neg
+    return m, np.maximum(s2 - m * m, 0.0)
 
 
 def fold_input_affine(W, bias, scale, shift):
@@ -118,6 +190,14 @@ class Program:
         self._raw = {}         # op index -> (K x coutp float32, taps, cin_p, coutp) of the 'f16' mode's convs (see blob())
         self._chunk_at = {}    # weight-region offset -> index into wchunks
         self.lane = 0          # convs emitted while this is 1 / 2 run on that side stream (ta_op_desc.variant bits 17..18)
+        # activation scales (module text above `act_moments`): per tensor and channel the expected (mean, variance) of what the
+        # ops write, in program order; `_fold[op]` keeps the un-scaled epilogue vectors until blob() knows every tensor's scale
+        self.stats = {}        # tensor -> [mean (C,), var (C,), written (C,) bool]
+        self._fold = {}
+        self.input_stats = None                # (mean, var) per input channel; default N(0, 1)
+        self.forced_scale = {}                 # tensor (or ('mid', op index): a dw+pw block's depthwise intermediate) -> exponent
+                                               # (tests: provoke / avoid the half-float range)
+        self.scales_enabled = not os.environ.get('TERRAN_AMD_NO_ACT_SCALES')     # A/B switch: every tensor stored unscaled
 
     def tensor(self, channels, halo, alias_of=-1, name=None, f32=False):
         """f32=True pins the tensor to plain float32 (outputs read by post-processing kernels / the host).
@@ -144,6 +224,68 @@ class Program:
             self.wchunks.append(b'\0' * pad)
         self.wbytes += arr.nbytes + pad
         return off
+
+    def _rewrite(self, off, arr):
+        """Replace the chunk reserved at `off` (same size)."""
+        k = self._chunk_at[off]
+        data = np.ascontiguousarray(arr, dtype=np.float32).tobytes()
+        assert len(data) == len(self.wchunks[k]), (len(data), len(self.wchunks[k]))
+        self.wchunks[k] = data
+
+    # ---- expected moments per tensor channel -------------------------------------------------------------------------
+    def _stats_of(self, tid):
+        c = self.tensors[tid][0]
+        a = self.tensors[tid][2]
+        if a >= 0:                                    # (N,1,1,H*W*C) view of tensor `a`: position-major, channel fastest
+            mu, var, wr = self._stats_of(a)
+            rep = c // len(mu)
+            return [np.tile(mu, rep), np.tile(var, rep), np.tile(wr, rep)]
+        if tid not in self.stats:
+            mu, var = np.zeros(c), np.ones(c)
+            if tid == self.input_tensor and self.input_stats is not None:
+                m_, v_ = self.input_stats
+                mu[:len(m_)], var[:len(v_)] = m_, v_
+            self.stats[tid] = [mu, var, np.zeros(c, bool)]
+            if tid == self.input_tensor:
+                self.stats[tid][2][:] = True
+        return self.stats[tid]
+
+    def _write_stats(self, tid, ch_off, mu, var):
+        st = self._stats_of(tid)
+        n = len(mu)
+        new = ~st[2][ch_off:ch_off + n]
+        # a slice written by several ops (ping-pong stage tensors): keep the larger expectation per channel
+        amax_old = np.abs(st[0][ch_off:ch_off + n]) + _ACT_SIGMAS * np.sqrt(st[1][ch_off:ch_off + n])
+        amax_new = np.abs(mu) + _ACT_SIGMAS * np.sqrt(var)
+        take = new | (amax_new > amax_old)
+        st[0][ch_off:ch_off + n][take] = mu[take]
+        st[1][ch_off:ch_off + n][take] = var[take]
+        st[2][ch_off:ch_off + n] = True
+
+    @staticmethod
+    def _conv_moments(full, bias, mu_in, var_in, groups, cout):
+        """full: (taps, cin_p, coutp) weights at their physical input positions; -> (mean, var) of the `cout` sums."""
+        taps, cin_p, coutp = full.shape
+        f64 = full.astype(np.float64)
+        wsum = f64.sum(0)                                          # (cin_p, coutp)
+        wsq = (f64 * f64).sum(0)
+        rho = _TAP_CORR if taps > 1 else 0.0
+        wvar = (1.0 - rho) * wsq + rho * wsum * wsum
+        mu = np.zeros(coutp)
+        var = np.zeros(coutp)
+        if groups > 1:
+            cg = cout // groups
+            for g in range(groups):
+                sl = slice(g * cg, (g + 1) * cg)
+                mu[sl] = mu_in[g * cin_p:(g + 1) * cin_p] @ wsum[:, sl]
+                var[sl] = var_in[g * cin_p:(g + 1) * cin_p] @ wvar[:, sl]
+        else:
+            mu = mu_in[:cin_p] @ wsum
+            var = var_in[:cin_p] @ wvar
+        b = np.zeros(coutp)
+        if bias is not None:
+            b[:cout] = np.asarray(bias, np.float64)
+        return (mu + b)[:cout], np.maximum(var[:cout], 0.0)
 
     def conv(self, tin, tout, W, bias, *, stride=1, pad=None, act=ACT_NONE, in_ch_off=0, ch_pos=None, cin_p=None,
              out_ch_off=0, cout_p=None, prelu=None, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
@@ -190,62 +332,112 @@ class Program:
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:K] = full.reshape(K, coutp)
         packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
-        wscale = 0
+        wexp = np.zeros(coutp, np.int64)
         prec = self.prec if precision is None else PRECISIONS[precision]      # a single op may run in another arithmetic mode
         raw = None
-        if prec == 4:
-            raw = (flat[:K].copy(), kh * kw, cin_p, coutp)       # re-packed in blob() when the input turns out to be TA_FMT_F16
         if prec in (3, 4):
-            packed, wscale = split_f16_rows(packed)
+            packed, wexp = split_f16_rows(packed)
         elif prec != 0:
             packed = split_bf16_rows(np.ascontiguousarray(packed))
+        if prec == 4:
+            raw = (flat[:K].copy(), kh * kw, cin_p, coutp, wexp)       # re-packed in blob() when the input turns out to be TA_FMT_F16
 
-        def vec(v):
+        def vec(v, fill=0.0):
             if v is None:
-                return -1
-            out = np.zeros(coutp, np.float32)
+                return -1, None
+            out = np.full(coutp, fill, np.float64)
             out[:cout] = np.asarray(v, dtype=np.float64)
-            return self._w(out)
-        if bias9 is not None:                                             # [9][coutp] in the place of the (absent) second output's scale
-            t9 = np.zeros((16, coutp), np.float32)
+            return self._w(out), out
+        fold = dict(wexp=wexp)
+        scale2_off = -1
+        if bias9 is not None:                                             # [16][coutp] in the place of the (absent) second output's scale
+            t9 = np.zeros((16, coutp), np.float64)
             t9[:, :cout] = bias9
-            scale2_off9 = self._w(t9)
+            scale2_off = self._w(t9)
+            fold['bias9'] = t9
             variant |= 1 << 16
+        else:
+            scale2_off, fold['scale2'] = vec(scale2)
+        bias_off, fold['bias'] = vec(bias if bias is not None else np.zeros(cout))
+        prelu_off, _ = vec(prelu)
+        shift2_off, fold['shift2'] = vec(shift2)
+        wus_off, _ = vec(np.ones(cout), fill=1.0)
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
-                  groups=groups, variant=variant | (int(k_split) << 8) | (self.lane << 17), pool=int(bool(pool)), wscale_log2=wscale, w_off=self._w(packed), bias_off=vec(bias), prelu_off=vec(prelu),
-                  scale2_off=scale2_off9 if bias9 is not None else vec(scale2),
-                  shift2_off=vec(shift2), macs_per_pixel=float(cout * cin * kh * kw))
+                  groups=groups, variant=variant | (int(k_split) << 8) | (self.lane << 17), pool=int(bool(pool)), wscale_log2=0,
+                  w_off=self._w(packed), bias_off=bias_off, prelu_off=prelu_off, scale2_off=scale2_off,
+                  shift2_off=shift2_off, wus_off=wus_off, macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
         if raw is not None:
             self._raw[len(self.ops)] = raw
+        self._fold[len(self.ops)] = fold
         self.ops.append(op)
+        # ---- expected moments of what this op writes
+        st_in = self._stats_of(tin)
+        span = cin_p * max(groups, 1)
+        mu, var = self._conv_moments(full, bias, st_in[0][in_ch_off:in_ch_off + span], st_in[1][in_ch_off:in_ch_off + span],
+                                     groups, cout)
+        mu, var = act_moments(mu, var, act, None if prelu is None else np.asarray(prelu, np.float64))
+        if res >= 0:
+            st_r = self._stats_of(res)
+            mu = mu + st_r[0][res_ch_off:res_ch_off + cout]
+            var = var + st_r[1][res_ch_off:res_ch_off + cout]
+        if pool:                                                          # max of four ~ independent values
+            mu, var = mu + 1.03 * np.sqrt(var), 0.49 * var
+        self._write_stats(tout, out_ch_off, mu, var)
+        if out2 >= 0:
+            s2, h2 = np.asarray(scale2, np.float64), np.asarray(shift2, np.float64)
+            self._write_stats(out2, out2_ch_off, mu * s2 + h2, var * s2 * s2)
 
     def dwconv(self, tin, tout, W, bias, *, stride=1, relu=True):
-        """W: (C,1,3,3) folded, bias (C,)."""
+        """W: (C,1,3,3) folded, bias (C,).  (The layer-by-layer detector program: float32 tensors, stored unscaled.)"""
         C = W.shape[0]
         w9 = np.asarray(W, dtype=np.float64).reshape(C, 9).T            # [9][C]
         op = dict(type=OP_DWCONV, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=C, coutp=_rup(C, 32), kh=3,
                   kw=3, stride=stride, pad=1, act=ACT_RELU if relu else ACT_NONE, res=-1, res_ch_off=0, res_up2=0,
                   out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(w9), bias_off=self._w(bias),
-                  prelu_off=-1, scale2_off=-1, shift2_off=-1, macs_per_pixel=float(C * 9))
+                  prelu_off=-1, scale2_off=-1, shift2_off=-1, wus_off=-1, macs_per_pixel=float(C * 9))
         op['in'] = tin
         self.ops.append(op)
+        st = self._stats_of(tin)
+        mu, var = self._dw_moments(w9, bias, st[0][:C], st[1][:C])
+        self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU if relu else ACT_NONE))
+
+    @staticmethod
+    def _dw_moments(w9, bias, mu_in, var_in):
+        w9 = np.asarray(w9, np.float64)
+        wsum, wsq = w9.sum(0), (w9 * w9).sum(0)
+        return (np.asarray(bias, np.float64) + mu_in * wsum,
+                var_in * ((1.0 - _TAP_CORR) * wsq + _TAP_CORR * wsum * wsum))
 
     def rfstem(self, tin, tout, Ws, bs, Wd, bd, Wp, bp):
         """RetinaFace front as ONE op: conv3x3 s2 (3 -> 8) -> depthwise 3x3 (8) -> 1x1 (8 -> 16), each + folded BN + ReLU.
         Ws (8,3,3,3) / bs (8,), Wd (8,1,3,3) / bd (8,), Wp (16,8,1,1) / bp (16,), all already folded."""
-        blob = np.concatenate([np.asarray(Ws, np.float64).reshape(8, 27).ravel(), np.asarray(bs, np.float64),
-                               np.asarray(Wd, np.float64).reshape(8, 9).T.ravel(), np.asarray(bd, np.float64),
-                               np.asarray(Wp, np.float64).reshape(16, 8).ravel(), np.asarray(bp, np.float64)])
+        parts = [np.asarray(Ws, np.float64).reshape(8, 27).ravel(), np.asarray(bs, np.float64),
+                 np.asarray(Wd, np.float64).reshape(8, 9).T.ravel(), np.asarray(bd, np.float64),
+                 np.asarray(Wp, np.float64).reshape(16, 8).ravel(), np.asarray(bp, np.float64)]
+        blob = np.concatenate(parts)
         assert blob.size == 448
         op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=16, coutp=32, kh=3, kw=3, stride=2,
                   pad=1, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1,
                   variant=0, pool=0, wscale_log2=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
-                  macs_per_pixel=float(8 * 27 + 16 * 8))
+                  wus_off=-1, macs_per_pixel=float(8 * 27 + 16 * 8))
         op['in'] = tin
+        self._fold[len(self.ops)] = dict(rfstem=parts)
         self.ops.append(op)
+        # moments: the frames are raw 0..255 BGR pixels (the kernel reads them itself: no float copy exists)
+        st = self._stats_of(tin)
+        ws = np.asarray(Ws, np.float64)                                   # (8, 3, 3, 3)
+        wsum, wsq = ws.sum((2, 3)), (ws * ws).sum((2, 3))                 # (8, 3)
+        mu = np.asarray(bs, np.float64) + wsum @ st[0][:3]
+        var = ((1.0 - _TAP_CORR) * wsq + _TAP_CORR * wsum * wsum) @ st[1][:3]
+        mu, var = act_moments(mu, var, ACT_RELU)
+        mu, var = self._dw_moments(np.asarray(Wd, np.float64).reshape(8, 9).T, bd, mu, var)
+        mu, var = act_moments(mu, var, ACT_RELU)
+        wp = np.asarray(Wp, np.float64).reshape(16, 8)
+        mu, var = np.asarray(bp, np.float64) + wp @ mu, (wp * wp) @ var
+        self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU))
 
     def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1, precision=None):
         """Depthwise 3x3 (stride 1 / 2, pad 1) + ReLU fused into the following 1x1 conv + ReLU (both BN-folded):
@@ -262,27 +454,41 @@ class Program:
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:C, :cout] = Wp.reshape(cout, C).T
         packed = np.ascontiguousarray(flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1))      # [slab][cout][32]
-        wscale = 0
+        wexp = np.zeros(coutp, np.int64)
         if prec == 3:
-            packed, wscale = split_f16_rows(packed)
-        bias = np.zeros(coutp, np.float32)
+            packed, wexp = split_f16_rows(packed)
+        bias = np.zeros(coutp, np.float64)
         bias[:cout] = np.asarray(bp, np.float64)
         w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
+        bd = np.asarray(bd, np.float64)
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=wscale, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
-                  scale2_off=self._w(w9), shift2_off=self._w(np.asarray(bd, np.float64)),
+                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  scale2_off=self._w(w9), shift2_off=self._w(bd), wus_off=self._w(np.ones(coutp)),
                   macs_per_pixel=float(cout * C))
         op['in'] = tin
+        # moments: depthwise (+ ReLU) -> the intermediate that is split into half floats in registers -> 1x1 (+ ReLU)
+        st = self._stats_of(tin)
+        mu, var = act_moments(*self._dw_moments(w9, bd, st[0][:C], st[1][:C]), ACT_RELU)
+        mid_amax = float(np.max(np.abs(mu) + _ACT_SIGMAS * np.sqrt(var))) if C else 0.0
+        self._fold[len(self.ops)] = dict(wexp=wexp, bias=bias, dw_w=w9, dw_b=bd, mid_amax=mid_amax)
         self.ops.append(op)
+        wp = Wp.reshape(cout, C)
+        mu2, var2 = bias[:cout] + wp @ mu, (wp * wp) @ var
+        self._write_stats(tout, 0, *act_moments(mu2, var2, ACT_RELU))
 
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
                   kw=2, stride=2, pad=0, act=0, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0,
                   prec=0, groups=1, variant=0, pool=0, wscale_log2=0, w_off=-1, bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
-                  macs_per_pixel=0.0)
+                  wus_off=-1, macs_per_pixel=0.0)
         op['in'] = tin
         self.ops.append(op)
+        st = self._stats_of(tin)
+        if typ == OP_MAXPOOL:
+            self._write_stats(tout, 0, st[0] + 1.03 * np.sqrt(st[1]), 0.49 * st[1])
+        else:
+            self._write_stats(tout, out_ch_off, st[0][in_ch_off:in_ch_off + ch].copy(), st[1][in_ch_off:in_ch_off + ch].copy())
 
     @classmethod
     def from_cache(cls, path):
@@ -365,28 +571,116 @@ class Program:
                     changed = True
         return fmt
 
+    def expected_amax(self, tid):
+        """Largest |x| the packer expects in tensor `tid` (|mean| + 6 sigma over the channels some op writes)."""
+        st = self._stats_of(tid)
+        w = st[2]
+        if not w.any():
+            return 0.0
+        return float(np.max(np.abs(st[0][w]) + _ACT_SIGMAS * np.sqrt(st[1][w])))
+
+    def tensor_scales(self):
+        """Exponent a per tensor: the tensor is STORED times 2^a (module text above `act_moments`).  0 everywhere unless the
+        program has half-float convs; 0 for the input, for tensors the host / post-processing kernels read (f32_only) and
+        for anything a plain depthwise op touches; tensors that share memory (aliases) or are copied raw (max-pool, channel
+        copy) share one exponent."""
+        n = len(self.tensors)
+        scales = [0] * n
+        if not self.scales_enabled or not any(op['type'] in (OP_CONV, OP_DWPW) and op['prec'] in (3, 4) for op in self.ops):
+            return scales
+        parent = list(range(n))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+
+        def union(a, b):
+            parent[find(a)] = find(b)
+        for t, (_, _, a) in enumerate(self.tensors):
+            if a >= 0:
+                union(t, a)
+        fixed = set(self.f32_only) | {self.input_tensor}
+        for op in self.ops:
+            if op['type'] in (OP_MAXPOOL, OP_COPYCH):
+                union(op['in'], op['out'])
+            elif op['type'] == OP_DWCONV:
+                fixed |= {op['in'], op['out']}
+        groups = {}
+        for t in range(n):
+            groups.setdefault(find(t), []).append(t)
+        for root, members in groups.items():
+            if any(t in fixed for t in members):
+                continue
+            forced = [self.forced_scale[t] for t in members if t in self.forced_scale]
+            if forced:
+                a = int(forced[0])
+            else:
+                amax = max(self.expected_amax(t) for t in members)
+                if not np.isfinite(amax) or amax <= 0.0:
+                    continue
+                a = int(np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(amax)), -40, 40))
+            for t in members:
+                scales[t] = a
+        return scales
+
     def blob(self):
         if getattr(self, '_blob', None) is not None:
             return self._blob
         hdr = np.zeros(1, HEADER_DT)
         tens = np.zeros(len(self.tensors), TENSOR_DT)
         fmts = self.tensor_formats()
+        scales = self.tensor_scales()
+        self.scales = scales
         for i, (c, h, a) in enumerate(self.tensors):
-            tens[i] = (c, h, a, fmts[i])
+            tens[i] = (c, h, a, fmts[i], scales[i])
         # 'f16' mode: a conv whose input tensor is stored as plain half floats (TA_FMT_F16) walks K in slabs of 64 channels --
         # a slab row is 64 halfs of ONE operand, not [hi x32 | lo x32] -- so its weights are re-packed here, in place (half
         # the bytes of the [hi | lo] image conv() reserved), once the formats are known
-        for i, (flat, taps, cin_p, coutp) in self._raw.items():
+        for i, (flat, taps, cin_p, coutp, wexp) in self._raw.items():
             op = self.ops[i]
             if fmts[op['in']] != FMT_F16:
                 continue
             assert cin_p % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
             K = taps * cin_p
-            rows = np.ldexp(flat.reshape(K // 64, 64, coutp).transpose(0, 2, 1), op['wscale_log2']).astype(np.float16)   # [slab][cout][64]
+            rows = np.ldexp(flat.reshape(K // 64, 64, coutp).transpose(0, 2, 1), wexp[None, :, None].astype(np.int32)).astype(np.float16)   # [slab][cout][64]
             k = self._chunk_at[op['w_off']]
             assert rows.nbytes * 2 == len(self.wchunks[k])
             self.wchunks[k] = rows.tobytes() + b'\0' * rows.nbytes
             op['n_slabs'] = K // 64
+        # epilogue vectors with every power of two folded in: sums arrive times 2^(a_in + s[co]), results leave times 2^a_out
+        self.mid_scales = {}
+        for i, f in self._fold.items():
+            op = self.ops[i]
+            a_in, a_out = scales[op['in']], scales[op['out']]
+            if op['type'] == OP_CONV:
+                up = np.ldexp(1.0, a_out)
+                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - a_in - f['wexp']).astype(np.int32)))
+                self._rewrite(op['bias_off'], f['bias'] * up)
+                if 'bias9' in f:
+                    self._rewrite(op['scale2_off'], f['bias9'] * up)
+                elif op['out2'] >= 0:
+                    a2 = scales[op['out2']]
+                    self._rewrite(op['scale2_off'], f['scale2'] * np.ldexp(1.0, a2 - a_out))
+                    self._rewrite(op['shift2_off'], f['shift2'] * np.ldexp(1.0, a2))
+            elif op['type'] == OP_DWPW:
+                # the depthwise result is split into half floats in registers (f16x3): it gets an exponent of its own
+                a_mid = 0
+                if op['prec'] == 3 and self.scales_enabled and f['mid_amax'] > 0 and np.isfinite(f['mid_amax']):
+                    a_mid = int(np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(f['mid_amax'])), -40, 40))
+                elif op['prec'] == 0:
+                    a_mid = a_in                                        # exact f32: any power of two gives the same bits
+                a_mid = int(self.forced_scale.get(('mid', i), a_mid))
+                self.mid_scales[i] = a_mid
+                self._rewrite(op['scale2_off'], f['dw_w'] * np.ldexp(1.0, a_mid - a_in))
+                self._rewrite(op['shift2_off'], f['dw_b'] * np.ldexp(1.0, a_mid))
+                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - a_mid - f['wexp']).astype(np.int32)))
+                self._rewrite(op['bias_off'], f['bias'] * np.ldexp(1.0, a_out))
+            elif op['type'] == OP_RFSTEM:
+                parts = list(f['rfstem'])
+                parts[4], parts[5] = parts[4] * np.ldexp(1.0, a_out), parts[5] * np.ldexp(1.0, a_out)
+                self._rewrite(op['w_off'], np.concatenate(parts))
         ops = np.zeros(len(self.ops), OP_DT)
         for i, op in enumerate(self.ops):
             for k, v in op.items():
@@ -432,6 +726,7 @@ def pack_openpose(sd, precision='f32'):
     P = Program(MODEL_OPENPOSE, precision)
     t = P.tensor(4, 1, name='input')
     P.input_tensor = t
+    P.input_stats = (np.array([-0.05, -0.05, -0.05, 0.0]), np.array([0.08, 0.08, 0.08, 0.0]))   # RGB / 255 - 0.5 of natural images
     X0 = P.tensor(OP_XCH, 3, name='X0')
     X1 = P.tensor(OP_XCH, 3, name='X1')
     items = arch.OPENPOSE_MODEL0
@@ -542,6 +837,7 @@ def pack_arcface(sd, precision='f32'):
     P = Program(MODEL_ARCFACE, precision)
     tin = P.tensor(4, 1, name='input')
     P.input_tensor = tin
+    P.input_stats = (np.array([-0.1, -0.1, -0.1, 0.0]), np.array([0.25, 0.25, 0.25, 0.0]))      # (BGR - 127.5) / 128 of face crops
     units = list(arch.arcface_units())
     second = bool(os.environ.get('TERRAN_AMD_ARCFACE_SECOND_OUTPUT'))
 
@@ -647,6 +943,7 @@ def pack_retinaface(sd, precision='f32', fused=None):
         fused = P.prec == 0 and not os.environ.get('TERRAN_AMD_NO_FUSED_DETECTOR')       # A/B switch
     tin = P.tensor(4, 1, alias_of=-2 if fused else -1, name='input')
     P.input_tensor = tin
+    P.input_stats = (np.array([110.0, 110.0, 110.0, 0.0]), np.array([4900.0, 4900.0, 4900.0, 0.0]))   # raw 0..255 BGR pixels
     eps = arch.RETINA_BASE_BN_EPS
 
     def cbr(key_conv, key_bn, e=eps, bias=False):

@@ -102,8 +102,11 @@ class RangeFallback:
 def packed_program(kind, state, precision):
     """Pack `state` for `kind`, going through the repack cache when the weights come from a checkpoint file.
 
-    Cache key = checkpoint id + precision + size/mtime of the .pth (terran/checkpoint.py:118-150 layout):
-    `$TERRAN_HOME/checkpoints/<id>.<precision>.<size>.<mtime>.v<blob version>.tam`.  Dict states (tests, bench) are packed directly."""
+    Cache key = checkpoint id + precision + size/mtime of the .pth (terran/checkpoint.py:118-150 layout) + blob version + a
+    hash of the packer's sources: `$TERRAN_HOME/checkpoints/<id>.<precision>.<size>.<mtime>.v<blob version>.<pack hash>.tam`.
+    With any pack-time switch set (pack.PACK_SWITCHES: A/B variants of the programs) the disk cache is bypassed in both
+    directions.  Dict states (tests, bench) are packed directly and memoised per (dict object, precision, switches): a state
+    dict must not be mutated in place between two models built from it (copy it: `dict(sd)`)."""
     from . import checkpoint, pack
     packer = getattr(pack, 'pack_%s' % kind)
     path = None
@@ -111,11 +114,12 @@ def packed_program(kind, state, precision):
         path = checkpoint.find_checkpoint_file(kind)
     elif isinstance(state, (str, os.PathLike)):
         path = state
-    if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE'):
+    switches = pack.active_switches()
+    if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE') or switches:
         # dict states (tests, bench, StreamPipeline's lanes): many models of one process are built from the SAME dict --
         # pack it once (a pack is seconds of numpy work; 16 lanes x 3 networks would spend a minute on it)
         sd = resolve_state(kind, state)
-        key = (kind, id(sd), precision, tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('TERRAN_AMD_'))))   # + pack-time switches
+        key = (kind, id(sd), precision, switches)
         with _memo_lock:
             hit = _pack_memo.get(key)
             if hit is not None and hit[0] is sd:
@@ -129,8 +133,8 @@ def packed_program(kind, state, precision):
                 _pack_memo.popitem(last=False)
         return prog
     st = os.stat(path)
-    cache = '%s.%s.%d.%d.v%d.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime),
-                                     pack.BLOB_VERSION)
+    cache = '%s.%s.%d.%d.v%d.%s.tam' % (os.path.splitext(str(path))[0], precision, st.st_size, int(st.st_mtime),
+                                        pack.BLOB_VERSION, pack.source_tag())
     if os.path.exists(cache):
         try:
             return pack.Program.from_cache(cache)

@@ -294,21 +294,27 @@ def test_fold_input_affine_equals_affine_then_zero_padded_conv():
 
 
 def test_split_f16_rows_carry_22_bits_and_a_power_of_two_scale():
-    """pack.split_f16_rows: weights x 2^s as [hi | lo] half floats; (hi + lo) 2^-s reproduces every weight within 2^-16 of
-    the layer's largest to 2^-21 relative, nothing overflows, and the detector's mixed-mode program gives the refiner's
-    64-channel tensors the half-split format while everything the float32 base touches stays float32."""
+    """pack.split_f16_rows: every OUTPUT CHANNEL's weights x 2^s[co] as [hi | lo] half floats; (hi + lo) 2^-s[co] reproduces
+    every weight within 2^-16 of its ROW's largest to 2^-21 relative whatever the other rows' magnitudes are (a BatchNorm with
+    a small gamma / sigma folded in gives a row whose weights are ALL far below the layer's maximum: with one exponent per
+    layer it kept ~17 bits), nothing overflows; and the detector's mixed-mode program gives the refiner's 64-channel
+    tensors the half-split format while everything the float32 base touches stays float32."""
     from terran_amd import pack, weights
     rng = np.random.default_rng(5)
-    w = (rng.normal(0, 0.04, (3, 64, 32)) * np.exp(rng.normal(0, 2.0, (3, 64, 1)))).astype(np.float32)   # rows of very different scale
+    w = (rng.normal(0, 0.04, (3, 64, 32)) * np.exp(rng.normal(0, 4.0, (1, 64, 1)))).astype(np.float32)   # rows 2^+-12 apart
+    assert np.abs(w).max((0, 2)).max() / np.abs(w).max((0, 2)).min() > 2.0 ** 16
     rows, s = pack.split_f16_rows(w)
+    assert s.shape == (64,)
     h16 = rows.view(np.float16).reshape(3, 64, 64)
     hi, lo = h16[..., :32].astype(np.float64), h16[..., 32:].astype(np.float64)
-    assert np.isfinite(hi).all() and np.abs(hi).max() < 2.0 ** 15 and 2.0 ** 13 <= np.abs(w).max() * 2.0 ** s < 2.0 ** 14
-    back = (hi + lo) * 2.0 ** -s
-    big = np.abs(w) >= np.abs(w).max() * 2.0 ** -16
-    assert big.mean() > 0.8
+    rowmax = np.abs(w).max((0, 2))
+    assert np.isfinite(hi).all() and np.abs(hi).max() < 2.0 ** 15
+    assert ((2.0 ** 13 <= rowmax * 2.0 ** s) & (rowmax * 2.0 ** s < 2.0 ** 14)).all()
+    back = (hi + lo) * 2.0 ** -s[None, :, None]
+    big = np.abs(w) >= rowmax[None, :, None] * 2.0 ** -16
+    assert big.mean() > 0.99
     assert (np.abs(back - w)[big] <= np.abs(w)[big] * 2.0 ** -21).all()
-    assert np.abs(back - w).max() <= np.abs(w).max() * 2.0 ** -23           # absolute error: one rounding of hi + lo at the top of the range
+    assert (np.abs(back - w).max((0, 2)) <= rowmax * 2.0 ** -23).all()      # absolute error per row: one rounding of hi + lo at the top of ITS range
     P = pack.pack_retinaface(weights.make_retinaface_state(), 'f16x3')
     fmt = P.tensor_formats()
     precs = {}
@@ -405,12 +411,67 @@ def test_f16_mode_packs_half_float_tensors_and_64_channel_slabs():
         else:
             assert i == 0 and op['n_slabs'] == 2                            # the stem: 27 -> 36 -> 2 slabs of 32
     op = P.ops[3]                                                           # a 64 -> 64 3x3 conv on a half-float tensor
-    flat, taps, cin_p, coutp = P._raw[3]
+    flat, taps, cin_p, coutp, wexp = P._raw[3]
     rows = np.frombuffer(wreg[op['w_off']:op['w_off'] + op['n_slabs'] * coutp * 128], np.float16).reshape(op['n_slabs'], coutp, 64)
-    want = np.ldexp(flat.reshape(-1, 64, coutp).transpose(0, 2, 1), op['wscale_log2']).astype(np.float16)
-    assert np.array_equal(rows, want) and 2.0 ** 13 <= np.abs(rows.astype(np.float32)).max() < 2.0 ** 14
+    want = np.ldexp(flat.reshape(-1, 64, coutp).transpose(0, 2, 1), wexp[None, :, None].astype(np.int32)).astype(np.float16)
+    rmax = np.abs(rows.astype(np.float32)).max((0, 2))[:op['cout']]
+    assert np.array_equal(rows, want) and ((2.0 ** 13 <= rmax) & (rmax < 2.0 ** 14)).all()      # per output channel
     assert (P.ops[-1]['variant'] >> 8) & 255 == 32 and P.ops[-1]['n_slabs'] == 392
     for packer, state in ((pack.pack_retinaface, weights.make_retinaface_state()), (pack.pack_openpose, weights.make_openpose_state())):
         precs = {o['prec'] for o in packer(state, 'f16').ops if o['type'] == pack.OP_CONV}
         assert 4 not in precs and 3 in precs
         assert packer(state, 'f16').blob() == packer(state, 'f16x3').blob()    # the SAME programs: every decision as in f16x3
+
+
+def test_activation_scales_follow_the_expected_magnitudes():
+    """pack.Program: per-channel (mean, variance) are propagated through the folded weights (Gaussian moments through ReLU /
+    PReLU) and every tensor of a program with half-float convs is stored times 2^a with its expected max |x| 2^a in
+    (2^9, 2^10]; consumers / producers get the powers of two folded into their epilogue vectors; programs without half-float
+    convs keep every exponent at 0; input, outputs and raw copies obey the loader's rules."""
+    from terran_amd import pack, weights
+    # (1) moments of a rectified Gaussian against sampling
+    rng = np.random.default_rng(0)
+    z = rng.normal(0.7, 1.3, 2_000_000)
+    m, v = pack.act_moments(np.array([0.7]), np.array([1.3 ** 2]), pack.ACT_RELU)
+    assert abs(m[0] - np.maximum(z, 0).mean()) < 3e-3 and abs(v[0] - np.maximum(z, 0).var()) < 6e-3
+    y = np.where(z > 0, z, 0.3 * z)
+    m, v = pack.act_moments(np.array([0.7]), np.array([1.3 ** 2]), pack.ACT_PRELU, np.array([0.3]))
+    assert abs(m[0] - y.mean()) < 3e-3 and abs(v[0] - y.var()) < 6e-3
+    # (2) the three networks: scales only where half-float convs exist, rules of the loader
+    for kind, sd in (('retinaface', weights.make_retinaface_state()), ('arcface', weights.make_arcface_state()),
+                     ('openpose', weights.make_openpose_state())):
+        packer = getattr(pack, 'pack_' + kind)
+        for prec in ('f32', 'bf16x3'):
+            P = packer(sd, prec)
+            P.blob()
+            assert set(P.scales) == {0}, (kind, prec)
+        P = packer(sd, 'f16x3')
+        P.blob()
+        assert P.scales[P.input_tensor] == 0 and all(P.scales[t] == 0 for t in P.f32_only)
+        used = [t for t in range(len(P.tensors)) if P.expected_amax(t) > 0 and t != P.input_tensor and t not in P.f32_only]
+        nz = [t for t in used if P.scales[t] != 0]
+        assert len(nz) > len(used) // 2, (kind, len(nz), len(used))
+        for op in P.ops:
+            if op['type'] in (pack.OP_MAXPOOL, pack.OP_COPYCH):
+                assert P.scales[op['in']] == P.scales[op['out']]
+        for t in nz:
+            if P.tensors[t][2] >= 0:
+                continue
+            a = P.expected_amax(t) * 2.0 ** P.scales[t]
+            assert a <= 2.0 ** 10 * 1.0001, (kind, t, a)             # grouped with a tensor of larger magnitude: may sit lower, never higher
+    # (3) gain invariance: scaling a layer's weights by 2^k moves its output tensor's exponent by -k and nothing else
+    rng = np.random.default_rng(1)
+
+    def prog(gain):
+        P = pack.Program(pack.MODEL_OPENPOSE, 'f16x3')
+        t0 = P.tensor(32, 1)
+        P.input_tensor = t0
+        t1, t2 = P.tensor(64, 1), P.tensor(64, 0, f32=True)
+        r = np.random.default_rng(3)
+        P.conv(t0, t1, r.normal(0, 0.1, (64, 32, 3, 3)) * gain, r.normal(0, 0.1, 64) * gain, act=pack.ACT_RELU)
+        P.conv(t1, t2, r.normal(0, 0.1, (64, 64, 3, 3)) / gain, r.normal(0, 0.1, 64))
+        P.outputs = [t2]
+        P.blob()
+        return P
+    a, b = prog(1.0), prog(2.0 ** 7)
+    assert b.scales[1] == a.scales[1] - 7 and b.scales[2] == a.scales[2] == 0
