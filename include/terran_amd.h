@@ -112,13 +112,14 @@ int ta_model_forward_crops(ta_model* m, const uint8_t* crops_nchw_bgr, int n);
 int ta_model_tensor_shape(ta_model* m, int tensor, int* n, int* c, int* h, int* w);
 int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst_nchw);
 
-/* f16x3 / f16 programs store every tensor times a power of two chosen at pack time (terran_amd/pack.py: tensor_scales);
- * ta_model_read_tensor divides it out.  ta_model_tensor_scale reports the exponent.  ta_model_debug_amax (tools / tests: does
- * the packer's expectation hold?): enable != 0 starts (or restarts, zeroed) the collection of the largest |x| every conv /
- * dw+pw op STORES (in stored, i.e. scaled, units); with out != NULL the maxima collected so far are copied out first:
- * out[2 i] = op i's output, out[2 i + 1] = the depthwise intermediate of a dw+pw op; capacity >= 2 x the number of ops
- * (TA_E_CAPACITY otherwise).  enable == 2 only reads (the collection goes on), enable == 0 ends it. */
-int ta_model_tensor_scale(const ta_model* m, int tensor, int* scale_log2);
+/* f16x3 / f16 programs store every CHANNEL of every tensor times a power of two chosen at pack time (terran_amd/pack.py:
+ * tensor_scales); ta_model_read_tensor divides it out.  ta_model_tensor_unscale copies the per-channel factors 2^-a[c]
+ * (ones where nothing is scaled; capacity >= the tensor's channels).  ta_model_debug_amax (tools / tests: does the packer's
+ * expectation hold?): enable != 0 starts (or restarts, zeroed) the collection of the largest |x| every conv / dw+pw op STORES
+ * (in stored, i.e. scaled, units: the figure that must stay below 65504); with out != NULL the maxima collected so far are
+ * copied out first: out[2 i] = op i's output, out[2 i + 1] = the depthwise intermediate of a dw+pw op; capacity >= 2 x the
+ * number of ops (TA_E_CAPACITY otherwise).  enable == 2 only reads (the collection goes on), enable == 0 ends it. */
+int ta_model_tensor_unscale(const ta_model* m, int tensor, float* out, int capacity);
 int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity);
 
 /* ---- RetinaFace.call (retinaface/wrapper.py:133-238) ------------------------------------ */

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* a, int na, con
 static int embed_tail(ta_model* m, int n, int normalize, float* out) {
   ta_ctx* ctx = m->ctx;
   const ta_tensor& E = m->tensors[m->hdr.outputs[0]];
-  if (E.scale_log2 != 0 || E.fmt != 0) return ta_fail(ctx, TA_E_INVALID, "arcface: the embedding tensor must be plain float32");
+  if (E.unscale_dev || E.fmt != 0) return ta_fail(ctx, TA_E_INVALID, "arcface: the embedding tensor must be plain float32");
   if (normalize) {
     ta_prof_scope scope(ctx, 3, (double)n * 512 * 8);
     hipLaunchKernelGGL(l2norm_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, E.dev, n, 512);

@@ -112,7 +112,10 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
     ts[i].c = m->tdesc[i].channels;
     ts[i].halo = m->tdesc[i].halo;
     ts[i].fmt = m->tdesc[i].fmt;
-    ts[i].scale_log2 = m->tdesc[i].scale_log2;
+    if (m->tdesc[i].unscale_off >= 0) {
+      ts[i].unscale_dev = (const float*)(m->weights_dev + m->tdesc[i].unscale_off);
+      ts[i].unscale_host = m->unscale_host[i].data();
+    }
     ts[i].n = n;
   }
   const int in_id = m->hdr.input_tensor;
@@ -421,8 +424,9 @@ int ta_model_run_ops(ta_model* m) {
         p.variant = op.variant & 255;
         if ((op.variant >> 16) & 1) p.bias9 = wptr(m, op.scale2_off);
         p.wus = wptr(m, op.wus_off);
-        p.res_scale = op.res >= 0 ? ldexpf(1.0f, to.scale_log2 - m->tensors[op.res].scale_log2) : 1.0f;
-        p.range_check = m->has_half_ops ? 1 : 0;
+        p.res_scale = 1.0f;                           // the packer gives a shortcut the exponents of the sum it joins
+        // a tensor no op reads is a float32 RESULT (embeddings, detector heads): nothing splits it into half floats, whatever it holds
+        p.range_check = (m->has_half_ops && (m->tensor_read[op.out] || (op.out2 >= 0 && m->tensor_read[op.out2]))) ? 1 : 0;
         p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
@@ -462,7 +466,7 @@ int ta_model_run_ops(ta_model* m) {
         p.prec = op.prec;
         p.wus = wptr(m, op.wus_off);
         p.res_scale = 1.0f;
-        p.range_check = m->has_half_ops ? 1 : 0;
+        p.range_check = (m->has_half_ops && m->tensor_read[op.out]) ? 1 : 0;
         p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
         p.amax_mid_slot = m->amax_dev ? m->amax_dev + 2 * oi + 1 : nullptr;
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
@@ -572,21 +576,33 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
       return ta_fail(ctx, TA_E_INVALID, "model blob: malformed op");
     }
   }
-  {  // activation scales: the host and the post-processing kernels read the input and the outputs as they are; tensors that share
-     // memory or are copied raw must agree; a shortcut may differ from the sum it joins by a power of two (ta_conv_launch::res_scale)
-    bool bad = false;
-    auto sc = [&](int t) { return m->tdesc[t].scale_log2; };
-    for (int t = 0; t < h.n_tensors; ++t) {
-      if (sc(t) < -64 || sc(t) > 64) bad = true;
-      const int a = m->tdesc[t].alias_of;
-      if (a >= 0 && (a >= h.n_tensors || sc(a) != sc(t))) bad = true;
+  {  // activation scales: per tensor an optional vector of per-channel powers of two in the weights region; the input is read by
+     // the pre-processing kernels as it is
+    bool bad = m->tdesc[h.input_tensor].unscale_off >= 0;
+    m->unscale_host.resize(h.n_tensors);
+    for (int t = 0; t < h.n_tensors && !bad; ++t) {
+      const int64_t off = m->tdesc[t].unscale_off;
+      if (off < 0) continue;
+      const size_t need = (size_t)m->tdesc[t].channels * sizeof(float);
+      if ((off & 3) || (size_t)off + need > (size_t)h.weights_bytes) {
+        bad = true;
+        break;
+      }
+      m->unscale_host[t].resize(m->tdesc[t].channels);
+      memcpy(m->unscale_host[t].data(), (const char*)blob + h.weights_off + off, need);
     }
-    if (sc(h.input_tensor) != 0) bad = true;
-    for (int i = 0; i < h.n_outputs; ++i)             // (an output may carry a scale: its reader applies it -- OpenPose's maps live in
-      if (h.outputs[i] < 0 || h.outputs[i] >= h.n_tensors) bad = true;   //  the ping-pong stage tensor -- or insists on 0)
+    for (int i = 0; i < h.n_outputs; ++i)
+      if (h.outputs[i] < 0 || h.outputs[i] >= h.n_tensors) bad = true;
+    m->tensor_read.assign(h.n_tensors, 0);
     for (auto& op : m->ops) {
-      if ((op.type == TA_OP_MAXPOOL || op.type == TA_OP_COPYCH) && sc(op.in) != sc(op.out)) bad = true;
-      if (op.type == TA_OP_DWCONV && (sc(op.in) != 0 || sc(op.out) != 0)) bad = true;
+      m->tensor_read[op.in] = 1;
+      if (op.res >= 0) m->tensor_read[op.res] = 1;
+    }
+    for (int t = 0; t < h.n_tensors; ++t)            // a view is read when its source is, and the other way round
+      if (m->tdesc[t].alias_of >= 0 && m->tdesc[t].alias_of < h.n_tensors && (m->tensor_read[t] || m->tensor_read[m->tdesc[t].alias_of]))
+        m->tensor_read[t] = m->tensor_read[m->tdesc[t].alias_of] = 1;
+    for (auto& op : m->ops) {
+      if (op.type == TA_OP_DWCONV && (m->tdesc[op.in].unscale_off >= 0 || m->tdesc[op.out].unscale_off >= 0)) bad = true;
       if ((op.type == TA_OP_CONV || op.type == TA_OP_DWPW) && (op.prec == 3 || op.prec == 4)) m->has_half_ops = true;
     }
     if (bad) {
@@ -660,9 +676,11 @@ int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity) {
   return TA_OK;
 }
 
-int ta_model_tensor_scale(const ta_model* m, int tensor, int* scale_log2) {
-  if (!m || !scale_log2 || tensor < 0 || tensor >= (int)m->tdesc.size()) return TA_E_INVALID;
-  *scale_log2 = m->tdesc[tensor].scale_log2;
+int ta_model_tensor_unscale(const ta_model* m, int tensor, float* out, int capacity) {
+  if (!m || !out || tensor < 0 || tensor >= (int)m->tdesc.size()) return TA_E_INVALID;
+  const int c = m->tdesc[tensor].channels;
+  if (capacity < c) return TA_E_CAPACITY;
+  for (int i = 0; i < c; ++i) out[i] = m->unscale_host[tensor].empty() ? 1.0f : m->unscale_host[tensor][i];
   return TA_OK;
 }
 
@@ -726,7 +744,6 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
   ta_ctx* ctx = m->ctx;
   const ta_tensor& t = m->tensors[tensor];
   if (!t.dev || ch_off < 0 || ch <= 0 || ch_off + ch > t.c) return ta_fail(ctx, TA_E_INVALID, "read_tensor: bad slice");
-  const float unscale = ldexpf(1.0f, -t.scale_log2);       // the tensor is stored times 2^scale_log2
   std::vector<float> host((size_t)m->run_n * t.hp() * t.wp() * t.c);
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TA_HIP(ctx, hipMemcpy(host.data(), t.dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -761,7 +778,7 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
           } else {
             v = host[t.off(i, y, x) + cc];
           }
-          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = v * unscale;
+          dst[(((size_t)i * ch + c) * t.h + y) * t.w + x] = t.unscale_host ? v * t.unscale_host[cc] : v;   // channel cc is stored times 2^a[cc]
         }
   return TA_OK;
 }

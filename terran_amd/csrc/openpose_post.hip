@@ -41,7 +41,8 @@ struct op_maps {
   int paf_ch, hm_ch;      // first PAF / heat-map channel
   int fmt;                // TA_FMT_F32 or TA_FMT_SPLIT (act_format.h)
   int h, w;
-  float unscale;          // the maps are stored times a power of two (ta_tensor::scale_log2): every read multiplies it out (exact)
+  const float* unscale;   // nullptr, or per channel of the tensor the power of two every read is multiplied with (exact): the network
+                          // stores channel c times 2^a[c] (ta_tensor::unscale_dev)
 };
 
 // ---- 1. bicubic x8 ------------------------------------------------------------------------------
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const op_maps m, int N, fl
     int col = q0 - 2 + lc;
     col = col < 0 ? 0 : (col > m.w - 1 ? m.w - 1 : col);
     const int ch = c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38);
-    bc_sm[(sr * 57 + c) * WP + lc] = ta_ld1(src + (size_t)row * m.row + (size_t)col * m.pix, ch, m.fmt) * m.unscale;
+    bc_sm[(sr * 57 + c) * WP + lc] = ta_ld1(src + (size_t)row * m.row + (size_t)col * m.pix, ch, m.fmt) * (m.unscale ? m.unscale[ch] : 1.0f);
   }
   __syncthreads();
   for (int task = threadIdx.x; task < 57 * 8 * tw; task += 256) {
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void op_planar_kernel(const op_maps m, int img
     const int cell = (int)(i % cells);
     const int c = (int)((i / cells) % 57), img = (int)(i / (cells * 57));
     const float* src = m.base + (size_t)(img_base + img) * m.img + m.off0 + (size_t)(cell / m.w) * m.row + (size_t)(cell % m.w) * m.pix;
-    out[i] = ta_ld1(src, c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38), m.fmt) * m.unscale;
+    out[i] = ta_ld1(src, c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38), m.fmt) * (m.unscale ? m.unscale[c < 38 ? m.paf_ch + c : m.hm_ch + (c - 38)] : 1.0f);
   }
 }
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(PK_T) void peaks_kernel(const op_work w) {
     wph = (float4*)(psm + (((size_t)h * wd * 4 + 15) & ~(size_t)15));   // 8
     cand = (unsigned long long*)(wph + 8);                           // OP_MAXP
     const float* src = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
-    for (int i = tid; i < h * wd; i += PK_T) smw[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt) * w.m.unscale;
+    for (int i = tid; i < h * wd; i += PK_T) smw[i] = ta_ld1(src + (size_t)(i / wd) * w.m.row + (size_t)(i % wd) * w.m.pix, w.m.hm_ch + part, w.m.fmt) * (w.m.unscale ? w.m.unscale[w.m.hm_ch + part] : 1.0f);
     sm = smw;
   }
   if (tid < 8) wph[tid] = ((const float4*)w.wphase)[tid];
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256) void limbs_kernel(const op_work w) {
     const float* srcm = w.m.base + (size_t)(w.img_base + img) * w.m.img + w.m.off0;
     for (int i = tid; i < mh * mw; i += 256) {
       const float* px = srcm + (size_t)(i / mw) * w.m.row + (size_t)(i % mw) * w.m.pix;
-      sx[i] = ta_ld1(px, w.m.paf_ch + chx, w.m.fmt) * w.m.unscale;
-      sy[i] = ta_ld1(px, w.m.paf_ch + chy, w.m.fmt) * w.m.unscale;
+      sx[i] = ta_ld1(px, w.m.paf_ch + chx, w.m.fmt) * (w.m.unscale ? w.m.unscale[w.m.paf_ch + chx] : 1.0f);
+      sy[i] = ta_ld1(px, w.m.paf_ch + chy, w.m.fmt) * (w.m.unscale ? w.m.unscale[w.m.paf_ch + chy] : 1.0f);
     }
     smx = sx;
     smy = sy;
@@ -1009,7 +1010,7 @@ int ta_openpose_run(ta_model* m, const ta_frames* frames, double scale, int capa
   mp.fmt = X.fmt;
   mp.h = X.h;
   mp.w = X.w;
-  mp.unscale = ldexpf(1.0f, -X.scale_log2);
+  mp.unscale = X.unscale_dev;
   TA_TRY(ta_range_enqueue(ctx));                 // behind the network, ahead of the grouping's syncs
   const int rc = op_postprocess_dev(ctx, mp, frames->n, scale, capacity, counts, keypoints, scores, required);
   return ta_range_finish(ctx, rc);               // f16x3: TA_E_RANGE when an activation left the half-float range
@@ -1039,7 +1040,7 @@ int ta_openpose_group(ta_ctx* ctx, const float* pafs, const float* heatmaps, int
   mp.fmt = TA_FMT_F32;
   mp.h = h;
   mp.w = w;
-  mp.unscale = 1.0f;
+  mp.unscale = nullptr;
   const int rc = op_postprocess_dev(ctx, mp, n, scale, capacity, counts, keypoints, scores, required);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(dev);
@@ -1126,7 +1127,7 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
     mp.fmt = TA_FMT_F32;
     mp.h = h;
     mp.w = w;
-    mp.unscale = 1.0f;
+    mp.unscale = nullptr;
     std::vector<float> up((size_t)n * 57 * 64 * h * w);
     const int rc = op_upsample_dev(ctx, mp, n, up.data());
     (void)hipStreamSynchronize(ctx->stream);

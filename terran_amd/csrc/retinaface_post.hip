@@ -494,7 +494,7 @@ int ta_retinaface_run(ta_model* m, const ta_frames* frames, float score_thr, flo
   ta_tensor heads[3];
   for (int l = 0; l < 3; ++l) {
     heads[l] = m->tensors[m->hdr.outputs[l]];
-    if (heads[l].scale_log2 != 0 || heads[l].fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "retinaface_run: the head tensors must be plain float32");
+    if (heads[l].unscale_dev || heads[l].fmt != TA_FMT_F32) return ta_fail(ctx, TA_E_INVALID, "retinaface_run: the head tensors must be plain float32");
   }
   const int rc = rf_postprocess_dev(ctx, heads, frames->n, frames->h, frames->w, 0, score_thr, nms_thr, capacity, counts, boxes,
                                     landmarks, scores, required);

@@ -46,10 +46,11 @@ struct ta_tensor_desc {
   int32_t alias_of;   // -1, or tensor id whose memory is viewed as (N,1,1,channels) (requires halo 0);
                       // -2: shape only, never materialised (the float input of a program whose first op reads the frames)
   int32_t fmt;        // TA_FMT_F32 / TA_FMT_SPLIT (act_format.h)
-  int32_t scale_log2; // the tensor is STORED times 2^scale_log2 (f16x3 / f16 programs: keeps the half-float words normal and
-                      // away from 65504; chosen by the packer from the expected magnitude, terran_amd/pack.py tensor_scales).
-                      // Producers and consumers have the factor folded into their per-channel epilogue vectors; debug taps
-                      // (ta_model_read_tensor) divide it out.  0 for the input and for every tensor the host / post-processing reads
+  int32_t unscale_off; // -1, or the byte offset (weights region) of [channels] floats 2^-a[c]: channel c of the tensor is STORED times
+                       // 2^a[c] (f16x3 / f16 programs: keeps every channel's half-float words normal and away from 65504; chosen by the
+                       // packer from the expected magnitudes, terran_amd/pack.py tensor_scales).  Consumers have 2^-a[c] folded into
+                       // their weight columns, producers 2^a[co] into their per-channel epilogue vectors; debug taps
+                       // (ta_model_read_tensor) and the pose post-processing multiply what they read with this vector
 };
 
 struct ta_op_desc {
@@ -74,10 +75,11 @@ struct ta_op_desc {
   int32_t wscale_log2;                // reserved (0): blob versions <= 7 kept one weight exponent per layer here
   int64_t w_off, bias_off, prelu_off, scale2_off, shift2_off;   // byte offsets in weights region, -1 none
   int64_t wus_off;                    // conv / dw+pw: [coutp] floats, the power of two the raw sums of output channel co are multiplied
-                                      // with before the bias is added: 2^(a_out - a_in - s[co]) -- s[co] the exponent row co of the packed
-                                      // half-float weights carries (their lo halves stay normal), a_in / a_out the activation scales of
-                                      // the tensors read / written; bias, border-class biases and the second output's affine are packed
-                                      // times 2^a_out already.  All ones outside the f16x3 / f16 programs
+                                      // with before the bias is added: 2^(a_out[co] - s[co]) -- s[co] the exponent row co of the packed
+                                      // half-float weights carries (their lo halves stay normal; the input channels' activation exponents
+                                      // are folded into the weight columns), a_out[co] the activation exponent of the channel written;
+                                      // bias, border-class biases and the second output's affine are packed times 2^a_out[co] already.
+                                      // All ones outside the f16x3 / f16 programs
   double macs_per_pixel;              // algorithmic MACs per output pixel (true, unpadded dims)
 };
 
@@ -233,7 +235,8 @@ struct ta_frames {
 struct ta_tensor {
   float* dev = nullptr;   // base of the padded allocation
   int n = 0, h = 0, w = 0, c = 0, halo = 0, fmt = 0;
-  int scale_log2 = 0;     // stored values = true values * 2^scale_log2 (ta_tensor_desc)
+  const float* unscale_dev = nullptr;   // [c] floats 2^-a[c] on the device, or nullptr: stored values = true values (ta_tensor_desc::unscale_off)
+  const float* unscale_host = nullptr;  // the same vector on the host (owned by the model)
   bool owns = true;
   int hp() const { return h + 2 * halo; }
   int wp() const { return w + 2 * halo; }
@@ -286,7 +289,8 @@ struct ta_conv_launch {
   const float* bias9;                          // border-class biases [16][coutp] of a conv with a folded input affine (nullptr: none)
   int late_b;                                  // tools only (TA_CONV_LATE_B): slab 0's pixel-row DMAs after ALL addresses are computed
   const float* wus;                            // [coutp]: the sums of channel co are multiplied by wus[co] before the bias (ta_op_desc.wus_off)
-  float res_scale;                             // the shortcut is added times this power of two (2^(a_out - a_res); 1 when the scales agree)
+  float res_scale;                             // the shortcut is added times this (1: the packer gives a shortcut and the sum it joins the same
+                                               // per-channel exponents; the field stays for programs that do not)
   int range_check;                             // 1: the program has half-float convs -- EVERY store of EVERY op is range-checked (a float32
                                                // tensor written by an exact-f32 op may be split into half floats by its consumer)
   int* range_flag;                             // set to 1 by an epilogue that stores |x| > 65504, inf or NaN while range_check is on
@@ -358,6 +362,8 @@ struct ta_model {
   bool has_half_ops = false;                    // any conv / dw+pw op with prec 3 / 4: every store is range-checked (ta_conv_launch::range_check)
   float* ones_dev = nullptr;                    // [max coutp] of 1.0f: the un-scale vector of ops packed without one
   unsigned* amax_dev = nullptr;                 // tools (ta_model_debug_amax): [2 * n_ops] largest |x| bit patterns (output, dw intermediate)
+  std::vector<char> tensor_read;                // per tensor: some op of the program reads it (results no op reads are not range-checked)
+  std::vector<std::vector<float>> unscale_host; // per tensor: host copy of its un-scale vector (empty: none)
   std::vector<char> weights_host_small;         // host copy of the few weights that travel as kernel arguments (TA_OP_RFSTEM)
   // small LRU of plans (lists of differently-sized images alternate between a few shapes); `tensors`,
   // `ktab_dev`, `ktab_off` mirror the active plan

@@ -56,7 +56,7 @@ SIGNATURES = {
     'ta_model_forward_frames': (c_int, [c_void_p, c_void_p]),
     'ta_model_forward_crops': (c_int, [c_void_p, c_void_p, c_int]),
     'ta_model_tensor_shape': (c_int, [c_void_p, c_int, P(c_int), P(c_int), P(c_int), P(c_int)]),
-    'ta_model_tensor_scale': (c_int, [c_void_p, c_int, P(c_int)]),
+    'ta_model_tensor_unscale': (c_int, [c_void_p, c_int, c_void_p, c_int]),
     'ta_model_debug_amax': (c_int, [c_void_p, c_int, c_void_p, c_int]),
     'ta_model_read_tensor': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'ta_retinaface_run': (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
@@ -366,10 +366,11 @@ class Model:
         self.ctx.check(self.ctx.lib.ta_model_read_tensor(self.h, tid, ch_off, ch, ptr(out)))
         return out
 
-    def tensor_scale(self, tid):
-        v = c_int()
-        self.ctx.check(self.ctx.lib.ta_model_tensor_scale(self.h, tid, C.byref(v)))
-        return v.value
+    def tensor_unscale(self, tid, channels):
+        """Per-channel factors 2^-a[c] the stored values of tensor `tid` are multiplied with to get the true ones."""
+        out = np.empty(channels, np.float32)
+        self.ctx.check(self.ctx.lib.ta_model_tensor_unscale(self.h, tid, ptr(out), channels))
+        return out
 
     def amax_collect(self, on=True):
         """Start (zeroed) / stop collecting the largest |x| every conv / dw+pw op stores (ta_model_debug_amax)."""

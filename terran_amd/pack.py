@@ -30,14 +30,14 @@ HEADER_DT = np.dtype({
     'offsets': [0, 4, 8, 12, 16, 20, 24, 28, 96, 104, 112, 120],
     'itemsize': 128,
 })
-TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4'), ('scale_log2', '<i4')])
+TENSOR_DT = np.dtype([('channels', '<i4'), ('halo', '<i4'), ('alias_of', '<i4'), ('fmt', '<i4'), ('unscale_off', '<i4')])
 FMT_F32, FMT_SPLIT, FMT_SPLIT16, FMT_F16 = 0, 1, 2, 3
 _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp', 'kh', 'kw', 'stride', 'pad',
            'act', 'res', 'res_ch_off', 'res_up2', 'out2', 'out2_ch_off', 'n_slabs', 'prec', 'groups', 'variant', 'pool', 'wscale_log2']
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off', 'wus_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 152 and TENSOR_DT.itemsize == 20
-BLOB_VERSION = 8            # 8: per-tensor activation scales (ta_tensor_desc.scale_log2) and per-output-channel un-scale vectors (ta_op_desc.wus_off) replace the per-layer wscale_log2; 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+BLOB_VERSION = 8            # 8: per-channel activation scales (ta_tensor_desc.unscale_off) and per-output-channel un-scale vectors (ta_op_desc.wus_off) replace the per-layer wscale_log2; 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
 # every environment switch a packer reads: a program packed with one of them set must never be served to a default run
@@ -119,17 +119,21 @@ def split_f16_rows(packed, exps=None):
 
 # ---- moment propagation (plan-time activation scales) -------------------------------------------------------------------
 # The half-float formats of the f16x3 / f16 modes keep all their bits for |x| in [2^-3, 65504] only (TA_FMT_SPLIT16:
-# the lo half goes subnormal below; TA_FMT_F16: 2^-14).  Every tensor of a program with half-float convs is therefore
-# STORED times a power of two 2^a chosen at pack time so that its largest expected |x| 2^a lands near 2^10 -- 64 x of
-# headroom to the end of the range, 13 binades of full precision below.  Consumers fold 2^-a into their per-channel
-# un-scale vector, producers fold 2^a into bias / un-scale (ReLU and PReLU are positively homogeneous), so the kernels do
-# no extra work.  The expectation comes from propagating per-channel (mean, variance) through the folded weights:
-# Gaussian moments through ReLU / PReLU, independent channels, half-correlated filter taps.  It only has to be right to
-# within a few binades: a tensor that still overflows raises the range flag (TA_E_RANGE -> the wrappers' exact-f32 re-run).
+# the lo half goes subnormal below; TA_FMT_F16: 2^-14).  Every CHANNEL of every tensor of a program with half-float convs is
+# therefore STORED times a power of two 2^a[c] chosen at pack time so that the channel's largest expected |x| 2^a[c] lands
+# near 2^10 -- 64 x of headroom to the end of the range, 13 binades of full precision below -- whatever the other channels
+# of the tensor do (trained networks spread their channels over orders of magnitude).  It costs the kernels nothing: a
+# consumer's weights absorb 2^-a[c] per INPUT channel (exact: powers of two, before the hi | lo split), a producer's
+# per-channel epilogue vectors absorb 2^a[co] (bias, un-scale; ReLU and PReLU are positively homogeneous), tensors that are
+# added (shortcuts), pooled, copied or aliased share their exponents.  The expectation comes from propagating per-channel
+# (mean, variance) through the folded weights: Gaussian moments through ReLU / PReLU, independent channels, half-correlated
+# filter taps.  It only has to be right to within a few binades: a channel that still overflows raises the range flag
+# (TA_E_RANGE -> the wrappers' exact-f32 re-run).
 _SQRT2, _SQRT2PI = np.sqrt(2.0), np.sqrt(2.0 * np.pi)
 _TAP_CORR = 0.5          # share of the variance that adds coherently over the taps of a k x k filter (smooth images)
 _ACT_TARGET_LOG2 = 10    # estimated max |x| 2^a in (2^9, 2^10]
 _ACT_SIGMAS = 6.0
+_CH_SPREAD = 8           # channel exponents of one tensor differ by at most this much
 
 
 def _erf(x):
@@ -192,7 +196,8 @@ class Program:
         self.lane = 0          # convs emitted while this is 1 / 2 run on that side stream (ta_op_desc.variant bits 17..18)
         # activation scales (module text above `act_moments`): per tensor and channel the expected (mean, variance) of what the
         # ops write, in program order; `_fold[op]` keeps the un-scaled epilogue vectors until blob() knows every tensor's scale
-        self.stats = {}        # tensor -> [mean (C,), var (C,), written (C,) bool]
+        self.stats = {}        # tensor -> [mean (C,), var (C,), written (C,) bool, amax (C,): bound on |x| the channel is expected to reach]
+        self._chunk_size = {}  # weight-region offset -> bytes of a chunk reserved for blob() to fill
         self._fold = {}
         self.input_stats = None                # (mean, var) per input channel; default N(0, 1)
         self.forced_scale = {}                 # tensor (or ('mid', op index): a dw+pw block's depthwise intermediate) -> exponent
@@ -225,11 +230,24 @@ class Program:
         self.wbytes += arr.nbytes + pad
         return off
 
-    def _rewrite(self, off, arr):
-        """Replace the chunk reserved at `off` (same size)."""
+    def _w_reserve(self, nbytes):
+        """Space for a chunk blob() fills once the activation scales are known (the packed weights of a conv)."""
+        off = self.wbytes
+        self._chunk_at[off] = len(self.wchunks)
+        self._chunk_size[off] = int(nbytes)
+        self.wchunks.append(None)
+        pad = (-int(nbytes)) % 256
+        if pad:
+            self.wchunks.append(b'\0' * pad)
+        self.wbytes += int(nbytes) + pad
+        return off
+
+    def _rewrite(self, off, arr, raw=False):
+        """Replace the chunk at `off` (same size)."""
         k = self._chunk_at[off]
-        data = np.ascontiguousarray(arr, dtype=np.float32).tobytes()
-        assert len(data) == len(self.wchunks[k]), (len(data), len(self.wchunks[k]))
+        data = arr if raw else np.ascontiguousarray(arr, dtype=np.float32).tobytes()
+        size = self._chunk_size.get(off, None if self.wchunks[k] is None else len(self.wchunks[k]))
+        assert len(data) == size, (len(data), size)
         self.wchunks[k] = data
 
     # ---- expected moments per tensor channel -------------------------------------------------------------------------
@@ -237,30 +255,48 @@ class Program:
         c = self.tensors[tid][0]
         a = self.tensors[tid][2]
         if a >= 0:                                    # (N,1,1,H*W*C) view of tensor `a`: position-major, channel fastest
-            mu, var, wr = self._stats_of(a)
+            mu, var, wr, am = self._stats_of(a)
             rep = c // len(mu)
-            return [np.tile(mu, rep), np.tile(var, rep), np.tile(wr, rep)]
+            return [np.tile(mu, rep), np.tile(var, rep), np.tile(wr, rep), np.tile(am, rep)]
         if tid not in self.stats:
             mu, var = np.zeros(c), np.ones(c)
             if tid == self.input_tensor and self.input_stats is not None:
                 m_, v_ = self.input_stats
                 mu[:len(m_)], var[:len(v_)] = m_, v_
-            self.stats[tid] = [mu, var, np.zeros(c, bool)]
+            self.stats[tid] = [mu, var, np.zeros(c, bool), np.abs(mu) + _ACT_SIGMAS * np.sqrt(var)]
             if tid == self.input_tensor:
                 self.stats[tid][2][:] = True
         return self.stats[tid]
 
-    def _write_stats(self, tid, ch_off, mu, var):
+    def _write_stats(self, tid, ch_off, mu, var, amax=None):
+        """amax: bound on |x| per channel (default |mean| + 6 sigma); a rectified channel passes the bound of its positive tail,
+        NOT the moments of the rectified variable -- a channel that is almost always zero still reaches that tail somewhere
+        in a batch of 10^7 pixels."""
         st = self._stats_of(tid)
         n = len(mu)
+        if amax is None:
+            amax = np.abs(mu) + _ACT_SIGMAS * np.sqrt(var)
         new = ~st[2][ch_off:ch_off + n]
-        # a slice written by several ops (ping-pong stage tensors): keep the larger expectation per channel
-        amax_old = np.abs(st[0][ch_off:ch_off + n]) + _ACT_SIGMAS * np.sqrt(st[1][ch_off:ch_off + n])
-        amax_new = np.abs(mu) + _ACT_SIGMAS * np.sqrt(var)
-        take = new | (amax_new > amax_old)
+        # a slice written by several ops (ping-pong stage tensors): moments of the writer with the larger bound, largest bound
+        take = new | (amax > st[3][ch_off:ch_off + n])
         st[0][ch_off:ch_off + n][take] = mu[take]
         st[1][ch_off:ch_off + n][take] = var[take]
+        st[3][ch_off:ch_off + n] = np.where(new, amax, np.maximum(amax, st[3][ch_off:ch_off + n]))
         st[2][ch_off:ch_off + n] = True
+
+    @staticmethod
+    def _act_bound(mu, var, act, slope=None):
+        """Bound on |act(z)| for z ~ N(mu, var): the 6-sigma tails of z pushed through the activation."""
+        sd = np.sqrt(np.maximum(var, 0.0))
+        hi, lo = mu + _ACT_SIGMAS * sd, _ACT_SIGMAS * sd - mu            # reach of the positive / negative tail
+        if act == ACT_NONE:
+            return np.maximum(hi, lo)
+        # a channel the moments call (almost) always off may still fire: the mean of a deep channel is the least certain number
+        # here, so a rectified channel is never given less than 4 sigma of reach
+        if act == ACT_RELU or slope is None:
+            return np.maximum(hi, 4.0 * sd)
+        a = np.abs(np.asarray(slope, np.float64))
+        return np.maximum(np.maximum(hi, a * lo), 4.0 * sd * np.maximum(a, 1.0))
 
     @staticmethod
     def _conv_moments(full, bias, mu_in, var_in, groups, cout):
@@ -331,16 +367,8 @@ class Program:
         full[:, np.asarray(ch_pos), :cout] = W.transpose(2, 3, 1, 0).reshape(kh * kw, cin, cout)
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:K] = full.reshape(K, coutp)
-        packed = flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)        # [slab][cout][32]
-        wexp = np.zeros(coutp, np.int64)
         prec = self.prec if precision is None else PRECISIONS[precision]      # a single op may run in another arithmetic mode
-        raw = None
-        if prec in (3, 4):
-            packed, wexp = split_f16_rows(packed)
-        elif prec != 0:
-            packed = split_bf16_rows(np.ascontiguousarray(packed))
-        if prec == 4:
-            raw = (flat[:K].copy(), kh * kw, cin_p, coutp, wexp)       # re-packed in blob() when the input turns out to be TA_FMT_F16
+        # the weights are packed by blob(): their columns absorb the input channels' activation exponents first
 
         def vec(v, fill=0.0):
             if v is None:
@@ -348,7 +376,7 @@ class Program:
             out = np.full(coutp, fill, np.float64)
             out[:cout] = np.asarray(v, dtype=np.float64)
             return self._w(out), out
-        fold = dict(wexp=wexp)
+        fold = dict(flat=flat, taps=kh * kw, cin_p=cin_p, K=K)
         scale2_off = -1
         if bias9 is not None:                                             # [16][coutp] in the place of the (absent) second output's scale
             t9 = np.zeros((16, coutp), np.float64)
@@ -366,11 +394,9 @@ class Program:
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
                   groups=groups, variant=variant | (int(k_split) << 8) | (self.lane << 17), pool=int(bool(pool)), wscale_log2=0,
-                  w_off=self._w(packed), bias_off=bias_off, prelu_off=prelu_off, scale2_off=scale2_off,
+                  w_off=self._w_reserve(n_slabs * coutp * 128), bias_off=bias_off, prelu_off=prelu_off, scale2_off=scale2_off,
                   shift2_off=shift2_off, wus_off=wus_off, macs_per_pixel=float(cout * cin * kh * kw))
         op['in'] = tin
-        if raw is not None:
-            self._raw[len(self.ops)] = raw
         self._fold[len(self.ops)] = fold
         self.ops.append(op)
         # ---- expected moments of what this op writes
@@ -378,17 +404,20 @@ class Program:
         span = cin_p * max(groups, 1)
         mu, var = self._conv_moments(full, bias, st_in[0][in_ch_off:in_ch_off + span], st_in[1][in_ch_off:in_ch_off + span],
                                      groups, cout)
-        mu, var = act_moments(mu, var, act, None if prelu is None else np.asarray(prelu, np.float64))
+        slope = None if prelu is None else np.asarray(prelu, np.float64)
+        bound = self._act_bound(mu, var, act, slope)
+        mu, var = act_moments(mu, var, act, slope)
         if res >= 0:
             st_r = self._stats_of(res)
             mu = mu + st_r[0][res_ch_off:res_ch_off + cout]
             var = var + st_r[1][res_ch_off:res_ch_off + cout]
+            bound = bound + st_r[3][res_ch_off:res_ch_off + cout]
         if pool:                                                          # max of four ~ independent values
             mu, var = mu + 1.03 * np.sqrt(var), 0.49 * var
-        self._write_stats(tout, out_ch_off, mu, var)
+        self._write_stats(tout, out_ch_off, mu, var, bound)
         if out2 >= 0:
             s2, h2 = np.asarray(scale2, np.float64), np.asarray(shift2, np.float64)
-            self._write_stats(out2, out2_ch_off, mu * s2 + h2, var * s2 * s2)
+            self._write_stats(out2, out2_ch_off, mu * s2 + h2, var * s2 * s2, np.abs(s2) * bound + np.abs(h2))
 
     def dwconv(self, tin, tout, W, bias, *, stride=1, relu=True):
         """W: (C,1,3,3) folded, bias (C,).  (The layer-by-layer detector program: float32 tensors, stored unscaled.)"""
@@ -402,7 +431,8 @@ class Program:
         self.ops.append(op)
         st = self._stats_of(tin)
         mu, var = self._dw_moments(w9, bias, st[0][:C], st[1][:C])
-        self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU if relu else ACT_NONE))
+        act = ACT_RELU if relu else ACT_NONE
+        self._write_stats(tout, 0, *act_moments(mu, var, act), self._act_bound(mu, var, act))
 
     @staticmethod
     def _dw_moments(w9, bias, mu_in, var_in):
@@ -437,7 +467,7 @@ class Program:
         mu, var = act_moments(mu, var, ACT_RELU)
         wp = np.asarray(Wp, np.float64).reshape(16, 8)
         mu, var = np.asarray(bp, np.float64) + wp @ mu, (wp * wp) @ var
-        self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU))
+        self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU), self._act_bound(mu, var, ACT_RELU))
 
     def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1, precision=None):
         """Depthwise 3x3 (stride 1 / 2, pad 1) + ReLU fused into the following 1x1 conv + ReLU (both BN-folded):
@@ -453,29 +483,26 @@ class Program:
         n_slabs = _rup(C, 32) // 32
         flat = np.zeros((n_slabs * 32, coutp), np.float32)
         flat[:C, :cout] = Wp.reshape(cout, C).T
-        packed = np.ascontiguousarray(flat.reshape(n_slabs, 32, coutp).transpose(0, 2, 1))      # [slab][cout][32]
-        wexp = np.zeros(coutp, np.int64)
-        if prec == 3:
-            packed, wexp = split_f16_rows(packed)
         bias = np.zeros(coutp, np.float64)
         bias[:cout] = np.asarray(bp, np.float64)
         w9 = np.asarray(Wd, np.float64).reshape(C, 9).T                                          # [9][C]
         bd = np.asarray(bd, np.float64)
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w(packed), bias_off=self._w(bias), prelu_off=-1,
+                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w_reserve(n_slabs * coutp * 128), bias_off=self._w(bias), prelu_off=-1,
                   scale2_off=self._w(w9), shift2_off=self._w(bd), wus_off=self._w(np.ones(coutp)),
                   macs_per_pixel=float(cout * C))
         op['in'] = tin
         # moments: depthwise (+ ReLU) -> the intermediate that is split into half floats in registers -> 1x1 (+ ReLU)
         st = self._stats_of(tin)
-        mu, var = act_moments(*self._dw_moments(w9, bd, st[0][:C], st[1][:C]), ACT_RELU)
-        mid_amax = float(np.max(np.abs(mu) + _ACT_SIGMAS * np.sqrt(var))) if C else 0.0
-        self._fold[len(self.ops)] = dict(wexp=wexp, bias=bias, dw_w=w9, dw_b=bd, mid_amax=mid_amax)
+        mu0, var0 = self._dw_moments(w9, bd, st[0][:C], st[1][:C])
+        mid_bound = self._act_bound(mu0, var0, ACT_RELU)                  # per channel: the depthwise result is per channel
+        mu, var = act_moments(mu0, var0, ACT_RELU)
+        self._fold[len(self.ops)] = dict(flat=flat, bias=bias, dw_w=w9, dw_b=bd, mid_bound=mid_bound)
         self.ops.append(op)
         wp = Wp.reshape(cout, C)
         mu2, var2 = bias[:cout] + wp @ mu, (wp * wp) @ var
-        self._write_stats(tout, 0, *act_moments(mu2, var2, ACT_RELU))
+        self._write_stats(tout, 0, *act_moments(mu2, var2, ACT_RELU), self._act_bound(mu2, var2, ACT_RELU))
 
     def simple(self, typ, tin, tout, in_ch_off=0, out_ch_off=0, ch=0):
         op = dict(type=typ, out=tout, in_ch_off=in_ch_off, cin=ch, out_ch_off=out_ch_off, cout=ch, coutp=0, kh=2,
@@ -486,9 +513,10 @@ class Program:
         self.ops.append(op)
         st = self._stats_of(tin)
         if typ == OP_MAXPOOL:
-            self._write_stats(tout, 0, st[0] + 1.03 * np.sqrt(st[1]), 0.49 * st[1])
+            self._write_stats(tout, 0, st[0] + 1.03 * np.sqrt(st[1]), 0.49 * st[1], st[3].copy())
         else:
-            self._write_stats(tout, out_ch_off, st[0][in_ch_off:in_ch_off + ch].copy(), st[1][in_ch_off:in_ch_off + ch].copy())
+            self._write_stats(tout, out_ch_off, st[0][in_ch_off:in_ch_off + ch].copy(), st[1][in_ch_off:in_ch_off + ch].copy(),
+                              st[3][in_ch_off:in_ch_off + ch].copy())
 
     @classmethod
     def from_cache(cls, path):
@@ -571,59 +599,108 @@ class Program:
                     changed = True
         return fmt
 
-    def expected_amax(self, tid):
-        """Largest |x| the packer expects in tensor `tid` (|mean| + 6 sigma over the channels some op writes)."""
+    def expected_amax(self, tid, per_channel=False):
+        """Largest |x| the packer expects in tensor `tid` (per channel: the bound of every channel some op writes, else 0)."""
         st = self._stats_of(tid)
-        w = st[2]
-        if not w.any():
-            return 0.0
-        return float(np.max(np.abs(st[0][w]) + _ACT_SIGMAS * np.sqrt(st[1][w])))
+        am = np.where(st[2], st[3], 0.0)
+        return am if per_channel else float(am.max()) if len(am) else 0.0
 
     def tensor_scales(self):
-        """Exponent a per tensor: the tensor is STORED times 2^a (module text above `act_moments`).  0 everywhere unless the
-        program has half-float convs; 0 for the input, for tensors the host / post-processing kernels read (f32_only) and
-        for anything a plain depthwise op touches; tensors that share memory (aliases) or are copied raw (max-pool, channel
-        copy) share one exponent."""
+        """Exponents a[c] per tensor and channel: channel c is STORED times 2^a[c] (module text above `act_moments`).  All 0
+        unless the program has half-float convs; 0 for the input, for tensors the host / post-processing kernels read
+        unscaled (f32_only) and for anything a plain depthwise op touches.  Channels that are added (shortcuts), pooled,
+        copied or seen through an alias share one exponent (union-find over (tensor, channel) nodes); a channel's exponent puts
+        the largest bound of its group in (2^9, 2^10], but no channel sits more than 2^_CH_SPREAD below its tensor's largest."""
         n = len(self.tensors)
-        scales = [0] * n
+        sizes = [t[0] for t in self.tensors]
+        scales = [np.zeros(c, np.int64) for c in sizes]
         if not self.scales_enabled or not any(op['type'] in (OP_CONV, OP_DWPW) and op['prec'] in (3, 4) for op in self.ops):
             return scales
-        parent = list(range(n))
+        base = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        parent = np.arange(base[-1], dtype=np.int64)
 
         def find(x):
-            while parent[x] != x:
-                parent[x] = parent[parent[x]]
-                x = parent[x]
-            return x
+            r = x
+            while parent[r] != r:
+                r = parent[r]
+            while parent[x] != r:
+                parent[x], x = r, parent[x]
+            return r
 
-        def union(a, b):
-            parent[find(a)] = find(b)
-        for t, (_, _, a) in enumerate(self.tensors):
+        def union_run(ta, ca, tb, cb, cnt):
+            for i in range(cnt):
+                ra, rb = find(base[ta] + ca + i), find(base[tb] + cb + i)
+                if ra != rb:
+                    parent[ra] = rb
+        for t, (c, _, a) in enumerate(self.tensors):
             if a >= 0:
-                union(t, a)
-        fixed = set(self.f32_only) | {self.input_tensor}
+                ca = sizes[a]
+                for p in range(c):
+                    ra, rb = find(base[t] + p), find(base[a] + p % ca)
+                    if ra != rb:
+                        parent[ra] = rb
+        fixed_t = set(self.f32_only) | {self.input_tensor}
         for op in self.ops:
-            if op['type'] in (OP_MAXPOOL, OP_COPYCH):
-                union(op['in'], op['out'])
+            if op['type'] == OP_MAXPOOL:
+                union_run(op['in'], 0, op['out'], 0, sizes[op['in']])
+            elif op['type'] == OP_COPYCH:
+                union_run(op['in'], op['in_ch_off'], op['out'], op['out_ch_off'], op['cin'])
             elif op['type'] == OP_DWCONV:
-                fixed |= {op['in'], op['out']}
-        groups = {}
+                fixed_t |= {op['in'], op['out']}
+            elif op['type'] == OP_CONV and op['res'] >= 0:
+                union_run(op['res'], op['res_ch_off'], op['out'], op['out_ch_off'], op['cout'])
+        amax = np.concatenate([self.expected_amax(t, per_channel=True) for t in range(n)])
+        # no channel more than 2^_CH_SPREAD below its tensor's largest: a channel's own bound is a noisier number than the tensor's
+        # (a mis-predicted weak channel must not be blown up into the end of the range), and 2^8 of relief already keeps a
+        # channel 2^14 below the tensor's largest inside the window where hi + lo carries all its bits
         for t in range(n):
-            groups.setdefault(find(t), []).append(t)
-        for root, members in groups.items():
-            if any(t in fixed for t in members):
-                continue
-            forced = [self.forced_scale[t] for t in members if t in self.forced_scale]
-            if forced:
-                a = int(forced[0])
+            seg = amax[base[t]:base[t + 1]]
+            if len(seg) and seg.max() > 0:
+                np.maximum(seg, np.where(seg > 0, seg.max() * 2.0 ** -_CH_SPREAD, 0.0), out=seg)
+        roots = np.array([find(i) for i in range(base[-1])], np.int64)
+        gmax = np.zeros(base[-1])
+        np.maximum.at(gmax, roots, amax)
+        fixed = np.zeros(base[-1], bool)
+        for t in fixed_t:
+            fixed[roots[base[t]:base[t + 1]]] = True
+        forced = {}
+        for t, e in self.forced_scale.items():
+            if isinstance(t, (int, np.integer)):
+                for r in roots[base[t]:base[t + 1]]:
+                    forced[int(r)] = int(e)
+        g = gmax[roots]
+        ok = np.isfinite(g) & (g > 0) & ~fixed[roots]
+        expo = np.zeros(base[-1], np.int64)
+        expo[ok] = np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(g[ok])), -40, 40).astype(np.int64)
+        for r, e in forced.items():
+            if not fixed[r]:
+                expo[roots == r] = e
+        return [expo[base[t]:base[t + 1]].copy() for t in range(n)]
+
+    def _pack_conv_weights(self, op, f, a_in):
+        """The [slab][cout][32] weight image of conv `op` with 2^-a_in[c] folded into the columns of input channel c (exact),
+        split into half floats / bf16 where the op's mode wants it.  -> (bytes, row exponents s[coutp])."""
+        flat, taps, cin_p, K = f['flat'], f['taps'], f['cin_p'], f['K']
+        coutp, groups = op['coutp'], max(op['groups'], 1)
+        cols = a_in[op['in_ch_off']:op['in_ch_off'] + cin_p * groups]
+        fs = flat
+        if np.any(cols != 0):
+            fs = flat.copy()
+            if groups > 1:
+                cg = op['cout'] // groups
+                for g_ in range(groups):
+                    e = -np.tile(cols[g_ * cin_p:(g_ + 1) * cin_p], taps).astype(np.int32)
+                    fs[:K, g_ * cg:(g_ + 1) * cg] = np.ldexp(flat[:K, g_ * cg:(g_ + 1) * cg], e[:, None])
             else:
-                amax = max(self.expected_amax(t) for t in members)
-                if not np.isfinite(amax) or amax <= 0.0:
-                    continue
-                a = int(np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(amax)), -40, 40))
-            for t in members:
-                scales[t] = a
-        return scales
+                fs[:K] = np.ldexp(flat[:K], -np.tile(cols[:cin_p], taps).astype(np.int32)[:, None])
+        n_slabs = flat.shape[0] // 32
+        packed = fs.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)          # [slab][cout][32]
+        wexp = np.zeros(coutp, np.int64)
+        if op['prec'] in (3, 4):
+            packed, wexp = split_f16_rows(packed)
+        elif op['prec'] != 0:
+            packed = split_bf16_rows(np.ascontiguousarray(packed))
+        return np.ascontiguousarray(packed, dtype=np.float32).tobytes(), wexp, fs
 
     def blob(self):
         if getattr(self, '_blob', None) is not None:
@@ -633,53 +710,78 @@ class Program:
         fmts = self.tensor_formats()
         scales = self.tensor_scales()
         self.scales = scales
+        # per tensor with a non-zero exponent anywhere: [C] floats 2^-a[c] in the weights region (debug taps and the pose
+        # post-processing multiply what they read with it)
+        unscale_off = []
         for i, (c, h, a) in enumerate(self.tensors):
-            tens[i] = (c, h, a, fmts[i], scales[i])
-        # 'f16' mode: a conv whose input tensor is stored as plain half floats (TA_FMT_F16) walks K in slabs of 64 channels --
-        # a slab row is 64 halfs of ONE operand, not [hi x32 | lo x32] -- so its weights are re-packed here, in place (half
-        # the bytes of the [hi | lo] image conv() reserved), once the formats are known
-        for i, (flat, taps, cin_p, coutp, wexp) in self._raw.items():
-            op = self.ops[i]
-            if fmts[op['in']] != FMT_F16:
-                continue
-            assert cin_p % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
-            K = taps * cin_p
-            rows = np.ldexp(flat.reshape(K // 64, 64, coutp).transpose(0, 2, 1), wexp[None, :, None].astype(np.int32)).astype(np.float16)   # [slab][cout][64]
-            k = self._chunk_at[op['w_off']]
-            assert rows.nbytes * 2 == len(self.wchunks[k])
-            self.wchunks[k] = rows.tobytes() + b'\0' * rows.nbytes
-            op['n_slabs'] = K // 64
-        # epilogue vectors with every power of two folded in: sums arrive times 2^(a_in + s[co]), results leave times 2^a_out
+            unscale_off.append(self._w(np.ldexp(np.ones(c), -scales[i].astype(np.int32))) if np.any(scales[i] != 0) else -1)
+            assert unscale_off[-1] < 2 ** 31
+            tens[i] = (c, h, a, fmts[i], unscale_off[-1])
+        # epilogue vectors with every power of two folded in: the sums of channel co arrive times 2^s[co] (the activation
+        # exponents of the input channels are inside the weights), the results leave times 2^a_out[co]
         self.mid_scales = {}
         for i, f in self._fold.items():
             op = self.ops[i]
-            a_in, a_out = scales[op['in']], scales[op['out']]
+            a_in = scales[op['in']]
+            a_out = np.zeros(op['coutp'], np.int64)
+            if op['type'] in (OP_CONV, OP_DWPW, OP_RFSTEM):
+                seg = scales[op['out']][op['out_ch_off']:op['out_ch_off'] + op['cout']]
+                a_out[:len(seg)] = seg
+            up = np.ldexp(1.0, a_out.astype(np.int32))
             if op['type'] == OP_CONV:
-                up = np.ldexp(1.0, a_out)
-                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - a_in - f['wexp']).astype(np.int32)))
+                data, wexp, fs = self._pack_conv_weights(op, f, a_in)
+                # 'f16' mode: a conv whose input tensor is stored as plain half floats (TA_FMT_F16) walks K in slabs of 64
+                # channels -- a slab row is 64 halfs of ONE operand, not [hi x32 | lo x32] -- half the bytes of the image reserved
+                if op['prec'] == 4 and fmts[op['in']] == FMT_F16:
+                    cin_p, K, coutp = f['cin_p'], f['K'], op['coutp']
+                    assert cin_p % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
+                    rows = np.ldexp(fs[:K].reshape(K // 64, 64, coutp).transpose(0, 2, 1), wexp[None, :, None].astype(np.int32)).astype(np.float16)   # [slab][cout][64]
+                    assert rows.nbytes * 2 == len(data)
+                    data = rows.tobytes() + b'\0' * rows.nbytes
+                    op['n_slabs'] = K // 64
+                    f['rows64'] = rows
+                f['wexp'] = wexp
+                self._rewrite(op['w_off'], data, raw=True)
+                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32)))
                 self._rewrite(op['bias_off'], f['bias'] * up)
                 if 'bias9' in f:
-                    self._rewrite(op['scale2_off'], f['bias9'] * up)
+                    self._rewrite(op['scale2_off'], f['bias9'] * up[None, :])
                 elif op['out2'] >= 0:
-                    a2 = scales[op['out2']]
-                    self._rewrite(op['scale2_off'], f['scale2'] * np.ldexp(1.0, a2 - a_out))
-                    self._rewrite(op['shift2_off'], f['shift2'] * np.ldexp(1.0, a2))
+                    a2 = np.zeros(op['coutp'], np.int64)
+                    seg = scales[op['out2']][op['out2_ch_off']:op['out2_ch_off'] + op['cout']]
+                    a2[:len(seg)] = seg
+                    self._rewrite(op['scale2_off'], f['scale2'] * np.ldexp(1.0, (a2 - a_out).astype(np.int32)))
+                    self._rewrite(op['shift2_off'], f['shift2'] * np.ldexp(1.0, a2.astype(np.int32)))
             elif op['type'] == OP_DWPW:
-                # the depthwise result is split into half floats in registers (f16x3): it gets an exponent of its own
-                a_mid = 0
-                if op['prec'] == 3 and self.scales_enabled and f['mid_amax'] > 0 and np.isfinite(f['mid_amax']):
-                    a_mid = int(np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(f['mid_amax'])), -40, 40))
+                # the depthwise result is split into half floats in registers (f16x3): per channel an exponent of its own
+                C = op['cin']
+                a_mid = np.zeros(C, np.int64)
+                if op['prec'] == 3 and self.scales_enabled:
+                    mb = f['mid_bound']
+                    okc = np.isfinite(mb) & (mb > 0)
+                    mbf = np.maximum(mb, mb[okc].max() * 2.0 ** -_CH_SPREAD) if okc.any() else mb
+                    a_mid[okc] = np.clip(_ACT_TARGET_LOG2 - np.ceil(np.log2(mbf[okc])), -40, 40).astype(np.int64)
                 elif op['prec'] == 0:
-                    a_mid = a_in                                        # exact f32: any power of two gives the same bits
-                a_mid = int(self.forced_scale.get(('mid', i), a_mid))
+                    a_mid = a_in[:C].copy()                             # exact f32: any power of two gives the same bits
+                if ('mid', i) in self.forced_scale:
+                    a_mid[:] = int(self.forced_scale[('mid', i)])
                 self.mid_scales[i] = a_mid
-                self._rewrite(op['scale2_off'], f['dw_w'] * np.ldexp(1.0, a_mid - a_in))
-                self._rewrite(op['shift2_off'], f['dw_b'] * np.ldexp(1.0, a_mid))
-                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - a_mid - f['wexp']).astype(np.int32)))
-                self._rewrite(op['bias_off'], f['bias'] * np.ldexp(1.0, a_out))
+                self._rewrite(op['scale2_off'], f['dw_w'] * np.ldexp(1.0, (a_mid - a_in[:C]).astype(np.int32))[None, :])
+                self._rewrite(op['shift2_off'], f['dw_b'] * np.ldexp(1.0, a_mid.astype(np.int32)))
+                fl = f['flat'].copy()
+                fl[:C] = np.ldexp(fl[:C], -a_mid.astype(np.int32)[:, None])
+                n_slabs = fl.shape[0] // 32
+                packed = np.ascontiguousarray(fl.reshape(n_slabs, 32, op['coutp']).transpose(0, 2, 1))
+                wexp = np.zeros(op['coutp'], np.int64)
+                if op['prec'] == 3:
+                    packed, wexp = split_f16_rows(packed)
+                self._rewrite(op['w_off'], np.ascontiguousarray(packed, dtype=np.float32).tobytes(), raw=True)
+                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32)))
+                self._rewrite(op['bias_off'], f['bias'] * up)
             elif op['type'] == OP_RFSTEM:
                 parts = list(f['rfstem'])
-                parts[4], parts[5] = parts[4] * np.ldexp(1.0, a_out), parts[5] * np.ldexp(1.0, a_out)
+                parts[4] = (parts[4].reshape(16, 8) * up[:16, None]).ravel()
+                parts[5] = parts[5] * up[:16]
                 self._rewrite(op['w_off'], np.concatenate(parts))
         ops = np.zeros(len(self.ops), OP_DT)
         for i, op in enumerate(self.ops):
@@ -693,7 +795,10 @@ class Program:
         hdr[0] = (MAGIC, BLOB_VERSION, self.kind, len(self.tensors), len(self.ops), self.input_tensor, len(self.outputs), outs,
                   t_off, o_off, w_off, self.wbytes)
         head = hdr.tobytes() + tens.tobytes() + ops.tobytes()
-        return head + b'\0' * (w_off - len(head)) + b''.join(self.wchunks)
+        for f in self._fold.values():                 # the float32 weight matrices are not needed any more
+            f.pop('flat', None)
+        self._blob = head + b'\0' * (w_off - len(head)) + b''.join(self.wchunks)     # a program is packed once
+        return self._blob
 
 
 # ---- BatchNorm folding -------------------------------------------------------------------

@@ -11,7 +11,7 @@ from terran_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3'])
+@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3', 'f16'])     # 'f16': the opt-in single-half embedder (detector / pose = f16x3)
 def precision(request):
     return request.param
 
@@ -123,7 +123,8 @@ def _rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
 
 
-NET_TOL = {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 1e-4}
+NET_TOL = {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 1e-4, 'f16': 2e-5}      # f16: detector and pose network ARE the f16x3 programs
+EMB_TOL = {'f32': (2e-5, 5e-6), 'f16x3': (2e-5, 5e-6), 'bf16x3': (2e-4, 5e-5), 'f16': (5e-3, 1e-3)}   # (raw rel, unit abs); f16: north_star's 1e-3
 
 
 def test_c2_fullsize_image_vs_oracle(states, precision):
@@ -166,7 +167,7 @@ def test_c3_fullsize_crops_vs_oracle(states, precision):
     unit = float(np.abs(arc.embed_crops(crops)[pick] - arcface_pre.l2_normalize(ref)).max())
     print('C3 %s: embeddings max rel err %.2e (of max|ref| = %.1f), unit embeddings max abs err %.2e' %
           (precision, err, np.abs(ref).max(), unit))
-    assert err <= (2e-4 if precision == 'bf16x3' else 2e-5) and unit <= (5e-5 if precision == 'bf16x3' else 5e-6)
+    assert err <= EMB_TOL[precision][0] and unit <= EMB_TOL[precision][1]
 
 
 def test_c3_fullsize_crops_single_half_embedder(states):
@@ -260,7 +261,9 @@ def test_c5_fullsize_frame_vs_oracle(states, precision):
             n_swapped += 1
             assert abs(float(a['score']) - float(r_dets[i]['score'])) < 1e-5        # only near-tied scores trade places
         n_off += int((vec(a) != vec(r_dets[j])).sum())
-    assert n_swapped <= max(2, len(dets) // 50) and n_off <= max(1, 14 * len(dets) // 1000), (n_swapped, n_off)
+    # measured over 224 frames (tests/test_gpu_decisions_vs_oracle.py): no swap, no off-by-one in any mode on these weights --
+    # the slack above is what two float32 implementations MAY do; this frame must show none of it
+    assert n_swapped == 0 and n_off == 0, (n_swapped, n_off)
     err = float(np.abs(feats - r_feats).max())
     assert len(poses) == len(r_poses) >= 3
     for a, b in zip(poses, r_poses):
@@ -268,4 +271,4 @@ def test_c5_fullsize_frame_vs_oracle(states, precision):
     print('C5 %s: %d detections (%d near-tied scores in swapped order, %d of %d integer coordinates off by one at a '
           'rounding half), embeddings max abs err %.2e, %d humans exact' %
           (precision, len(dets), n_swapped, n_off, 14 * len(dets), err, len(poses)))
-    assert err <= (5e-5 if precision == 'bf16x3' else 5e-6)
+    assert err <= EMB_TOL[precision][1]
