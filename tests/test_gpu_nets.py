@@ -215,3 +215,77 @@ def test_retinaface_net(ctx, states, precision, fused):
             _close(mine_fg, ref_fg, what='fg prob s%d' % s)
             _close(bbox, outs[3 * i + 1], what='bbox s%d' % s)
             _close(lmk, outs[3 * i + 2], what='lmk s%d' % s)
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_worksize_nets_vs_reference_goldens(ctx, states, precision):
+    """The device at the working sizes of BASELINE configs[4] against what the REFERENCE modules produced there
+    (tests/golden/worksize_*.npz: one 184 x 327 OpenPose forward, one 416 x 739 RetinaFace head set) -- not against the
+    oracle, which shares the product's layer tables."""
+    from terran_amd import lib
+    _prec[0] = precision
+    g = golden('worksize_openpose.npz')
+    n, h, w = (int(v) for v in g['shape'])
+    m = lib.Model(ctx, pack.pack_openpose(states('openpose'), precision))
+    m.forward_frames(ctx.upload(synth.frames(int(g['frames_seed']), n, h, w)))
+    _close(m.read('pafs'), g['pafs'], what='golden pafs 184x327')
+    _close(m.read('heatmaps'), g['heatmaps'], what='golden heatmaps 184x327')
+    m.free()
+    g = golden('worksize_retinaface.npz')
+    n, h, w = (int(v) for v in g['shape'])
+    m = lib.Model(ctx, pack.pack_retinaface(states('retinaface'), precision))
+    m.forward_frames(ctx.upload(synth.frames(int(g['frames_seed']), n, h, w)))
+    for i, s in enumerate((32, 16, 8)):
+        head = m.read('head%d' % s)
+        fg = 1.0 / (1.0 + np.exp(head[:, 0:2].astype(np.float64) - head[:, 2:4].astype(np.float64)))
+        for j, mine in enumerate((fg, head[:, 4:12], head[:, 12:32])):
+            k = 3 * i + j
+            if k < 6:
+                _close(mine, g['out%d' % k][:, 2:4] if j == 0 else g['out%d' % k], what='golden out%d' % k)
+            else:
+                ref4 = g['out%d_every4' % k]
+                _close(mine[:, :, ::4, ::4], ref4[:, 2:4] if j == 0 else ref4, what='golden out%d (every 4th pixel)' % k)
+                if j:
+                    sums = mine.astype(np.float64).sum((0, 2, 3))
+                    assert np.abs(sums - g['out%d_sum' % k]).max() <= NET_TOL[precision] * g['out%d_abs_sum' % k].max()
+    m.free()
+
+
+@pytest.mark.parametrize('precision', PRECISIONS + ['f16'])
+def test_wild_statistics_nets_vs_reference_goldens(ctx, states, precision):
+    """The device on weights with trained-looking statistics against the REFERENCE modules run on the same weights
+    (tests/golden/wild_*.npz).  'f16' = the opt-in single-half embedder: measured outside north_star's 1e-3 on these weights
+    (DESIGN section 4), held to 5e-3 here; its detector / pose programs are f16x3's."""
+    from terran_amd import lib
+    _prec[0] = 'f16x3' if precision == 'f16' else precision
+    g = golden('wild_retinaface.npz')
+    n, h, w = (int(v) for v in g['shape'])
+    m = lib.Model(ctx, pack.pack_retinaface(states('wild_retinaface'), precision))
+    m.forward_frames(ctx.upload(synth.frames(int(g['frames_seed']), n, h, w)))
+    for i, s in enumerate((32, 16, 8)):
+        head = m.read('head%d' % s)
+        fg = 1.0 / (1.0 + np.exp(head[:, 0:2].astype(np.float64) - head[:, 2:4].astype(np.float64)))
+        _close(fg, g['out%d' % (3 * i)][:, 2:4], what='wild fg prob s%d' % s)
+        _close(head[:, 4:12], g['out%d' % (3 * i + 1)], what='wild bbox s%d' % s)
+        _close(head[:, 12:32], g['out%d' % (3 * i + 2)], what='wild lmk s%d' % s)
+    assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
+    m.free()
+    g = golden('wild_openpose.npz')
+    n, h, w = (int(v) for v in g['shape'])
+    m = lib.Model(ctx, pack.pack_openpose(states('wild_openpose'), precision))
+    m.forward_frames(ctx.upload(synth.frames(int(g['frames_seed']), n, h, w)))
+    _close(m.read('pafs'), g['pafs'], what='wild golden pafs')
+    _close(m.read('heatmaps'), g['heatmaps'], what='wild golden heatmaps')
+    assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
+    m.free()
+    g = golden('wild_arcface.npz')
+    m = lib.Model(ctx, pack.pack_arcface(states('wild_arcface'), precision))
+    m.forward_crops(g['crops'])
+    out = m.read('embedding')[:, :, 0, 0]
+    _close(out, g['embeddings'], tol=2e-2 if precision == 'f16' else None, what='wild golden embedding')
+    unit = lambda e: e / np.sqrt((e.astype(np.float64) ** 2).sum(1, keepdims=True))
+    err = float(np.abs(unit(out) - unit(g['embeddings'])).max())
+    print('  wild arcface %s: unit embeddings max abs err %.2e' % (precision, err))
+    assert err <= {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 2e-4, 'f16': 5e-3}[precision]
+    assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
+    m.free()
