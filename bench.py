@@ -233,7 +233,10 @@ def run(args):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    from terran_amd import Detection, Recognition, Estimation, runtime, shard, video
+    from terran_amd import Detection, Recognition, Estimation, affinity, runtime, shard, video
+    # this rank's host threads (task threads, reader threads, the pinned staging they touch first) on the cores of the socket
+    # its GPU hangs off: at 2 600 frames/s a rank moves 16 GB/s through pinned memory (terran_amd/affinity.py)
+    placement = affinity.bind(device_index)
 
     # Host side: a pipeline of three host threads per GPU, each with its own context (HIP stream + scratch):
     # detection, embedding (fed the detections of its batch through a queue) and pose.  Kernels of the streams
@@ -520,7 +523,8 @@ def run(args):
     def ingest_leg(res):
         # -- ingest: frames come from host memory through RawVideoReader (pinned double buffers, own upload stream per
         #    pipeline), the region's per-step results are gathered in rank order on rank 0 inside the timed region
-        k = max(4 * L, min(max(args.steps, 48), 60))      # >= 48 steps: a 20-step region is mostly pipeline fill and drain
+        per_step = res['elapsed'] / res['steps']
+        k = max(4 * L, 48, int(np.ceil(args.side_seconds / per_step)))     # a region of >= --side-seconds (a 20-step one is mostly fill and drain)
         gathered = []
         lock = threading.Lock()
 
@@ -602,6 +606,41 @@ def run(args):
                                         'algorithmic_gflop_per_step': round(r3['klass']['conv_igemm']['work'] / 1e9, 1)}
         face_state['F'] = F
 
+    # BASELINE configs[1] (RetinaFace 640 x 640, batch 32) at N > 1: every rank runs its own batches, aggregate images/s over a
+    # region of >= 1 s (barrier + sync on both sides, max over ranks).  north_star asks for the 640 x 640 figures beside the
+    # 1080p ones at every N; at N = 1 `per_model` carries the same row with its roofline.
+    c2_multi = None
+    if use_dist and not args.single_mode:
+        from terran_amd import retinaface, synth
+        det640 = retinaface.RetinaFace(device=device_index, state=sd_r, precision=primary, ctx=pipes[0].ctxs[0])
+        fr640 = pipes[0].ctxs[0].upload(synth.frames(1 + rank, 32, 640, 640))
+
+        def c2_region(k):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                det640.call_frames(fr640)
+            sync()
+            e = time.perf_counter() - t0
+            t = torch.tensor([e], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        c2_region(3)
+        e0 = c2_region(20)
+        k2 = max(20, int(np.ceil(1.0 / (e0 / 20))))
+        e1 = c2_region(k2)
+        c2_multi = {'images_per_s': round(32 * k2 * world / e1, 1), 'batches_per_rank': k2, 'seconds': round(e1, 3),
+                    'ms_per_batch': round(e1 / k2 * 1e3, 3), 'precision': primary,
+                    'what': 'RetinaFace.call on a resident 32 x 640 x 640 batch per rank (network + decode + NMS + result lists), '
+                            'aggregate over all ranks'}
+        fr640.free()
+        det640.model.free()
+    placements = [affinity.describe(placement)]
+    if use_dist:
+        gathered_pl = [None] * world
+        dist.all_gather_object(gathered_pl, affinity.describe(placement), group=gather_group)
+        placements = gathered_pl
+
     result = None
     if rank == 0:
         dets, feats, poses = out
@@ -641,6 +680,7 @@ def run(args):
                 'pose_peaks_per_frame': round(pipes[0].ctxs[2].pose_stats()[0] / float(args.batch), 1),
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
+                'host_placement_per_rank': placements,
                 'streams_per_gpu': 4 * L if args.lane_embedders else 3 * L + 1,
                 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                 'batches_in_flight_per_gpu': L,
@@ -689,6 +729,8 @@ def run(args):
             result['roofline_f16_embedder'] = others['f16']['roofline']
         if 'ingest' in head:
             result['ingest'] = head['ingest']
+        if c2_multi is not None:
+            result['c2_retinaface_640'] = c2_multi
         if isinstance(head.get('ingest', {}).get('value'), float):
             result['value_ingest'] = head['ingest']['value']
         result['other_precisions'] = others

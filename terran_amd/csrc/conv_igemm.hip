@@ -137,10 +137,10 @@ __device__ __forceinline__ unsigned ta_amax4(unsigned m, const f32x4& v) {
 // end of an epilogue: raise the flag; tools (ta_model_debug_amax) also collect the maximum itself per op
 __device__ __forceinline__ void ta_range_report(const ta_conv_launch& p, unsigned amax) {
   if (amax > TA_F16_MAX_BITS) *p.range_flag = 1;
-  if (p.amax_slot) {
+  if (p.amax_index >= 0) {                        // tools: the slots live behind the flag word (ta_ctx::range_flag, TA_AMAX_SLOT0)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
-    if ((threadIdx.x & 63) == 0 && amax) atomicMax(p.amax_slot, amax);
+    if ((threadIdx.x & 63) == 0 && amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index, amax);
   }
 }
 // ReLU that keeps a NaN a NaN (`v > 0 ? v : 0` turns it into 0 and hides it from the range guard)
@@ -169,11 +169,19 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
       for (int j = 0; j < 4; ++j) slope[a][j] = *(const f32x4*)(p.prelu + co_base + a * 32 + 8 * j);
   }
   const int co_max = p.cout - 4;
-  f32x4 us[WM_TILES][4];                          // per-channel power of two: weight-row exponent and activation scales (ta_op_desc.wus_off)
+  // per-channel power of two (weight-row exponent and activation scale of the channel written, ta_op_desc.wus_off): the
+  // accumulators are scaled in place, one short-lived vector at a time -- exact, so acc * us + bias rounds once like the fma
+  // would, and no [WM_TILES][4] vector array stays live next to the bias through the epilogue (register pressure of the kernel)
 #pragma unroll
   for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) us[a][j] = *(const f32x4*)(p.wus + co_base + a * 32 + 8 * j);
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 u = *(const f32x4*)((p.bias + p.coutp) + co_base + a * 32 + 8 * j);
+#pragma unroll
+      for (int b = 0; b < WN_TILES; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a][b][4 * j + e] *= u[e];
+    }
   unsigned amax = 0;                              // largest |x| stored, as a bit pattern (ta_range_report)
 #pragma unroll
   for (int b = 0; b < WN_TILES; ++b) {
@@ -190,7 +198,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us[a][j][e], bias[a][j][e]);   // us == 1: acc + bias
+        for (int e = 0; e < 4; ++e) v[a][j][e] = acc[a][b][4 * j + e] + bias[a][j][e];
     if (p.bias9) {                                      // border pixels: the class's bias instead (see ta_border_class)
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
       if (cls != TA_INTERIOR) {
@@ -200,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
           for (int j = 0; j < 4; ++j) {
             const f32x4 b9 = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co_base + a * 32 + 8 * j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(acc[a][b][4 * j + e], us[a][j][e], b9[e]);
+            for (int e = 0; e < 4; ++e) v[a][j][e] = acc[a][b][4 * j + e] + b9[e];
           }
       }
     }
@@ -235,7 +243,7 @@ __device__ __forceinline__ void conv_epilogue(const ta_conv_launch& p, f32x16 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[a][j][e] = __builtin_fmaf(r4[a][j][e], p.res_scale, v[a][j][e]);   // res_scale == 1: v + r
+          for (int e = 0; e < 4; ++e) v[a][j][e] += r4[a][j][e];
     }
     float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
     if (pix_ok) {
@@ -290,14 +298,19 @@ template <int BN, int BM, int NT>
 __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, const float* lds, int ct0, int pt0, int tid,
                                                     int HoWo, int ks);
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+// DIRECT_OK: the kernel also carries the direct epilogue (stores straight from the accumulators) for channel slices that are
+// not on 8-channel boundaries.  Only the generic kernel does: the fallback sets the register budget of whatever kernel it is
+// compiled into (its bias / slope / value arrays are live next to all accumulators), and no layer of the three networks takes it.
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool DIRECT_OK = false>
 __device__ __forceinline__ void conv_finish_sym(const ta_conv_launch& p, f32x16 (&acc)[WM_TILES][WN_TILES], float* lds, int ct0,
                                                 int pt0, int wm, int wn, int tid, int lane, int HoWo) {
   constexpr int BN = WAVES_M * WM_TILES * 32, BM = WAVES_N * WN_TILES * 32, NCH = BN / 4;
-  const bool staged = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
-  if (!staged) {
-    conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
-    return;
+  if constexpr (DIRECT_OK) {
+    const bool staged = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
+    if (!staged) {
+      conv_epilogue<WM_TILES, WN_TILES>(p, acc, ct0 + wm * WM_TILES * 32, pt0 + wn * WN_TILES * 32, lane, HoWo);
+      return;
+    }
   }
   __syncthreads();                                  // every wave is done reading operand fragments: the ring is free
 #pragma unroll
@@ -386,7 +399,7 @@ __device__ __forceinline__ void conv_slab_mma(const float* st, f32x16 (&acc)[WM_
   }
 }
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;   // output channels per workgroup
   constexpr int BM = WAVES_N * WN_TILES * 32;   // pixels per workgroup
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ta_conv_launch p) {
     conv_slab_mma<WM_TILES, WN_TILES, PREC>(st, acc, a_row0, b_row0, fsw, fcb, lane);
   }
 
-  conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
+  conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES, DIRECT>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
 }
 
 // K-slab order of the uniform-K kernels (conv_igemm_pipe, conv_igemm_split): channel block OUTERMOST, then ky, then kx.
@@ -756,6 +769,11 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the fragment reads of slab s (issued in the previous step) must have RETURNED before the barrier hands its stage to the
+    // next DMA: with pre-split or float32 operands nothing consumes them before the barrier (convert() is empty), so the
+    // compiler's own wait sits in front of their first MFMA -- behind the barrier.  (A read that lost the race returned the
+    // next slab's bytes: one run in a few hundred, found when the kernel's register allocation changed.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // slab s+1 visible; all waves are done reading slab s from LDS
     asm volatile("" ::: "memory");
     if (s + STAGES < S) issue(s + STAGES, free_stage);
@@ -921,10 +939,10 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   }
   if constexpr (PREC != PREC_F32) {
     if (dw_amax > TA_F16_MAX_BITS) *p.range_flag = 1;
-    if (p.amax_mid_slot) {
+    if (p.amax_index >= 0) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) dw_amax = max(dw_amax, (unsigned)__shfl_xor((int)dw_amax, o));
-      if (lane == 0 && dw_amax) atomicMax(p.amax_mid_slot, dw_amax);
+      if (lane == 0 && dw_amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index + 1, dw_amax);
     }
   }
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
@@ -1105,7 +1123,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
   const int n4 = p.cout - co >= 8 ? 2 : (p.cout - co >= 4 ? 1 : 0);    // valid 4-channel halves (cout % 4 == 0)
   if (n4 == 0) return;
   const f32x4 bias0 = *(const f32x4*)(p.bias + co), bias1 = *(const f32x4*)(p.bias + co + 4);   // padded to coutp
-  const f32x4 us0 = *(const f32x4*)(p.wus + co), us1 = *(const f32x4*)(p.wus + co + 4);          // per-channel power of two
+  const f32x4 us0 = *(const f32x4*)(p.bias + p.coutp + co), us1 = *(const f32x4*)(p.bias + p.coutp + co + 4);   // per-channel power of two (ta_op_desc.wus_off)
   f32x4 sl0 = {0, 0, 0, 0}, sl1 = {0, 0, 0, 0}, sc0 = sl0, sc1 = sl0, sh0 = sl0, sh1 = sl0;
   if (p.act == TA_ACT_PRELU) {
     sl0 = *(const f32x4*)(p.prelu + co);
@@ -1131,7 +1149,7 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
       v.b = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v.a[e] = __builtin_fmaf(v.a[e], us0[e], bias0[e]);
+        v.a[e] = __builtin_fmaf(v.a[e], us0[e], bias0[e]);     // us == 1 outside the half-float programs: v + bias
         v.b[e] = __builtin_fmaf(v.b[e], us1[e], bias1[e]);
         if (p.act == TA_ACT_RELU) {
           v.a[e] = ta_relu(v.a[e]);
@@ -1200,13 +1218,13 @@ __device__ __forceinline__ void conv_epilogue_drain(const ta_conv_launch& p, con
         const ta_f32x8 r = ta_ld8(rs, p.res_ch + co, p.res_fmt);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v.a[e] = __builtin_fmaf(r.a[e], p.res_scale, v.a[e]);     // res_scale == 1: v + r
-          v.b[e] = __builtin_fmaf(r.b[e], p.res_scale, v.b[e]);
+          v.a[e] += r.a[e];          // (a shortcut carries the exponents of the sum it joins: pack.Program.tensor_scales)
+          v.b[e] += r.b[e];
         }
       } else {
         const f32x4 r = ta_ld4(rs, p.res_ch + co, p.res_fmt);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v.a[e] = __builtin_fmaf(r[e], p.res_scale, v.a[e]);
+        for (int e = 0; e < 4; ++e) v.a[e] += r[e];
       }
     }
     float* o = p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0;
@@ -1272,8 +1290,8 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
   float bias[8], sl[8], sc[8], sh[8], us[8];
   *(f32x4*)bias = *(const f32x4*)(p.bias + co);
   *(f32x4*)(bias + 4) = *(const f32x4*)(p.bias + co + 4);
-  *(f32x4*)us = *(const f32x4*)(p.wus + co);
-  *(f32x4*)(us + 4) = *(const f32x4*)(p.wus + co + 4);
+  *(f32x4*)us = *(const f32x4*)(p.bias + p.coutp + co);             // per-channel power of two, stored behind the bias (ta_op_desc.wus_off)
+  *(f32x4*)(us + 4) = *(const f32x4*)(p.bias + p.coutp + co + 4);
   if (ACT == TA_ACT_PRELU) {
     *(f32x4*)sl = *(const f32x4*)(p.prelu + co);
     *(f32x4*)(sl + 4) = *(const f32x4*)(p.prelu + co + 4);
@@ -1285,7 +1303,6 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     *(f32x4*)(sh + 4) = *(const f32x4*)(p.shift2 + co + 4);
   }
   auto chan = [](int ch) { return F16 == 2 ? (unsigned)(2 * ch) : ta_split_chan(ch); };
-  const float rsc = p.res_scale;
   unsigned amax = 0;
   char* const ob = (char*)p.out + chan(p.out_ch + co);
   const char* const rb = RES ? (const char*)p.res + chan(p.res_ch + co) : nullptr;
@@ -1326,7 +1343,7 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      v[e] = __builtin_fmaf(v[e], us[e], bb[e]);       // us = 2^(a_out - a_in - s[co]); all ones in the bf16 programs: v + bb
+      v[e] = __builtin_fmaf(v[e], us[e], bb[e]);       // us = 2^(a_out[co] - s[co]); all ones in the bf16 programs: v + bb
       if (ACT == TA_ACT_RELU) v[e] = ta_relu(v[e]);
       if (ACT == TA_ACT_PRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
     }
@@ -1336,8 +1353,8 @@ __device__ __forceinline__ void conv_drain_fast(const ta_conv_launch& p, const f
         float h0, h1, l0 = 0.f, l1 = 0.f;
         ta_unpack2<F16 != 0>(rh[i], h0, h1);
         if (F16 != 2) ta_unpack2<F16 != 0>(rl[i], l0, l1);
-        v[2 * i] = __builtin_fmaf(h0 + l0, rsc, v[2 * i]);           // rsc == 1: v + r
-        v[2 * i + 1] = __builtin_fmaf(h1 + l1, rsc, v[2 * i + 1]);
+        v[2 * i] += h0 + l0;
+        v[2 * i + 1] += h1 + l1;
       }
     }
     if (POOL) {
@@ -1455,9 +1472,10 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     s_begin = (int)(((long long)ks * p.n_slabs) / p.k_split);
     S = (int)(((long long)(ks + 1) * p.n_slabs) / p.k_split) - s_begin;
   }
-  // LDS-staged, line-coalesced epilogue whenever every channel slice involved is 8-aligned (always when K-split:
-  // the raw sums go to the workspace)
-  const bool lds_epilogue = p.k_split > 1 || (((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0);
+  // The epilogue is ALWAYS the LDS-staged, line-coalesced one: the launcher gives this kernel only layers whose channel
+  // slices are 8-aligned (variant_eligible).  The direct epilogue (stores straight from the accumulators) used to be
+  // compiled in as a fallback no layer of the three networks ever took -- and set the register budget of the whole kernel:
+  // 168 VGPRs + 121 spilled in the 12-wave variants, 241 in the 8-wave ones, against 143 and no spill without it.
 
   if (wave >= NC) {
     // ================= producer =================
@@ -1504,23 +1522,23 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       const size_t off = (size_t)img * p.in_img + (size_t)(y * p.stride) * p.in_row + (size_t)(x * p.stride) * p.in_pix +
                          p.in_off0 + in_ch;
       b_off[q - QA] = (unsigned)((off - off0) * 4 + lchunk * 16);
-      if (!p.late_b) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + (q * NP + pw) * 256);      // slab 0 -> stage 0
+      if (!(p.probe & 4)) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + (q * NP + pw) * 256);      // slab 0 -> stage 0
     }
-    if (!p.late_b) wb.advance();
+    if (!(p.probe & 4)) wb.advance();
     auto issue_b = [&](int stage) {                 // pixel rows of the next slab in K order
 #pragma unroll
       for (int q = QA; q < NI; ++q) ta_dma16(b_base + wb.b_off, b_off[q - QA], lds + stage * STAGE + (q * NP + pw) * 256);
       wb.advance();
     };
     if (wave == NC) TA_STAMP(9);                    // producer: addresses ready, slab 0 issued
-    if (p.late_b) issue_b(0);                        // tools (TA_CONV_LATE_B): the round-2 order, all addresses first
+    if ((p.probe & 4)) issue_b(0);                        // tools (TA_CONV_LATE_B): the round-2 order, all addresses first
     if (S > 1) issue_b(1);
     if (wave == NC) TA_STAMP(10);                    // producer: first slabs issued
     int stage = 2;                                  // stage the next issued slab goes to
     for (int s = 0; s < S; ++s) {
       // slab s must have landed; issue order was [A0 A1 B0 B1] then [A B] per slab, and vmcnt counts in issue order
-      if (p.probe && s > 0) {                        // tools only (timing ablation): fewer DMAs in flight
-        if (p.probe == 1 && s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+      if ((p.probe & 3) && s > 0) {                        // tools only (timing ablation): fewer DMAs in flight
+        if ((p.probe & 3) == 1 && s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else if (s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - QA) : "memory");
       else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
@@ -1528,12 +1546,12 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
       __builtin_amdgcn_s_barrier();                 // B_s: slab s landed (all producers); consumers have drained slab s-1
       asm volatile("" ::: "memory");
       if (s + 2 < S) {
-        if (p.probe != 2) issue_a(s + 2, stage);
-        if (!p.probe) issue_b(stage);
+        if ((p.probe & 3) != 2) issue_a(s + 2, stage);
+        if (!(p.probe & 3)) issue_b(stage);
         stage = stage == 2 ? 0 : stage + 1;
       }
     }
-    if (lds_epilogue) {                             // help drain the parked tile: twice the lanes for the epilogue math
+    {                                               // help drain the parked tile: twice the lanes for the epilogue math
       __builtin_amdgcn_s_barrier();                 // E0
       __builtin_amdgcn_s_barrier();                 // E1
       asm volatile("" ::: "memory");
@@ -1660,20 +1678,19 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
   mma(F0);
   mma(F1);
   if (wave == 0) TA_STAMP(3);                       // consumer: main loop done (last MFMAs issued)
-  if (lds_epilogue) {
+  {
     __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: the ring can be reused
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(5);                     // consumer: past E0
     conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
     if (wave == 0) TA_STAMP(6);                     // consumer: accumulators parked (LDS writes issued)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and executed: a raw s_barrier does not wait for them
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
     if (wave == 0) TA_STAMP(7);                     // consumer: past E1
     bool done = false;
     if constexpr (PREC != PREC_F32) done = conv_drain_dispatch<BN, BM, 64 * (NC + NP), (PREC == PREC_F16 ? 2 : (prec_half(PREC) ? 1 : 0))>(p, lds, ct0, pt0, tid, HoWo);
     if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
-  } else {
-    conv_epilogue<2, 2>(p, acc, ct0 + cm * 64, pt0 + cn * 64, lane, HoWo);
   }
   if (wave == 0) TA_STAMP(4);                       // consumer: epilogue stores issued
 }
@@ -1689,7 +1706,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
     const int rem = pix - img * HoWo;
     const int y = rem / p.Wo, x = rem - y * p.Wo;
     f32x4 v = *(const f32x4*)(p.bias + co);
-    const f32x4 us = *(const f32x4*)(p.wus + co);
+    const f32x4 us = *(const f32x4*)((p.bias + p.coutp) + co);
     if (p.bias9) {
       const int cls = ta_border_class(y, x, p.Ho, p.Wo);
       if (cls != TA_INTERIOR) v = *(const f32x4*)(p.bias9 + (size_t)cls * p.coutp + co);
@@ -1711,7 +1728,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ta_conv_launch
       const int ry = p.res_up2 ? (y >> 1) : y, rx = p.res_up2 ? (x >> 1) : x;
       const f32x4 r = ta_ld4(p.res + (size_t)img * p.res_img + (size_t)ry * p.res_row + (size_t)rx * p.res_pix + p.res_off0, p.res_ch + co, p.res_fmt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(r[e], p.res_scale, v[e]);
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
     }
     ta_st4(p.out + (size_t)img * p.out_img + (size_t)y * p.out_row + (size_t)x * p.out_pix + p.out_off0, p.out_ch + co,
            p.out_fmt, v);
@@ -1758,7 +1775,7 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;     // slot 15: launches whose epilogue ran the specialised drain
   }
   static const bool late_b = getenv("TA_CONV_LATE_B") != nullptr;             // tools: A/B of the early slab-0 pixel-row DMAs
-  q.late_b = late_b ? 1 : 0;
+  if (late_b) q.probe |= 4;
   static const bool no_fast_div = getenv("TA_CONV_NO_FASTDIV") != nullptr;    // tools: A/B of the division-free set-up
   q.fast_div = (!no_fast_div && grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
   {
@@ -1784,14 +1801,23 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
-  auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC>;
   {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC);
     ctx->note_kernel(name);
   }
-  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
-  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  // two instances: the usual one drains through LDS only; channel slices off the 8-channel boundaries (or the A/B switch
+  // TA_CONV_DIRECT_EPILOGUE) take the one that also carries the direct epilogue -- and pays for it in registers
+  const bool staged = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
+  if (staged) {
+    auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, false>;
+    TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  } else {
+    auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, true>;
+    TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  }
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }
@@ -1839,10 +1865,8 @@ static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
 int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p_in.M <= 0) return TA_OK;
   ta_conv_launch p = p_in;
-  if (!p.wus) return ta_fail(ctx, TA_E_INVALID, "dw+pw: no un-scale vector");
-  if (!(p.res_scale > 0.f)) p.res_scale = 1.f;
   p.range_flag = ctx->range_flag;
-  if ((p.prec != PREC_F32 && p.prec != PREC_F16X3) || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || p.dw_c % 4 || !p.dw_w ||
+  if ((p.prec != PREC_F32 && p.prec != PREC_F16X3) || p.in_fmt != TA_FMT_F32 || p.coutp % 32 || p.cout % 4 || (p.out_ch & 7) || p.dw_c % 4 || !p.dw_w ||
       !p.dw_bias || p.n_slabs * 32 < p.dw_c)
     return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 or f16x3 mode, float32 input activations and 4-aligned channels");
   ta_prof_scope scope(ctx, 0, flops);
@@ -1862,14 +1886,16 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
 static bool variant_eligible(int v, const ta_conv_launch& p) {
   const bool split_in = p.in_fmt == ta_split_fmt_of(p.prec);   // what the split-role kernel reads: float32 in f32 mode, else the mode's pre-split format
   const bool deep = p.uniform_k && (p.n_slabs >= 2 || p.prec == PREC_F16);   // f16 mode: a 1x1 conv over 64 channels is ONE slab of 64
+  // the split-role kernel has the LDS-staged epilogue only: every channel slice on an 8-channel boundary
+  const bool staged = ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && (p.cout & 3) == 0;
   switch (v) {
     case TA_CV_GENERIC: return p.in_fmt == TA_FMT_F32 && !p.group_cout;
-    case TA_CV_PIPE64: return deep && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || (split_in && p.prec != PREC_F16));
-    case TA_CV_PIPE128: return deep && p.coutp % 128 == 0 && !p.group_cout && p.in_fmt == TA_FMT_F32;
+    case TA_CV_PIPE64: return deep && staged && p.coutp % 64 == 0 && !p.group_cout && (p.in_fmt == TA_FMT_F32 || (split_in && p.prec != PREC_F16));
+    case TA_CV_PIPE128: return deep && staged && p.coutp % 128 == 0 && !p.group_cout && p.in_fmt == TA_FMT_F32;
     case TA_CV_SPLIT_2x2:
     case TA_CV_SPLIT_2x2_P8:
-    case TA_CV_SPLIT_2x4: return deep && split_in && p.coutp % 128 == 0;
-    case TA_CV_SPLIT_1x4: return deep && split_in && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0);
+    case TA_CV_SPLIT_2x4: return deep && split_in && staged && p.coutp % 128 == 0;
+    case TA_CV_SPLIT_1x4: return deep && split_in && staged && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0);
   }
   return false;
 }
@@ -1929,9 +1955,6 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   if (p.in_fmt != TA_FMT_F32 && p.in_fmt != ta_split_fmt_of(p.prec))
     return ta_fail(ctx, TA_E_INVALID, "conv: input tensor format %d does not belong to precision mode %d", p.in_fmt, p.prec);
   p.range_flag = ctx->range_flag;
-  if (!p.wus) return ta_fail(ctx, TA_E_INVALID, "conv: no un-scale vector");
-  if (!(p.res_scale > 0.f)) p.res_scale = 1.f;
-  if (prec_half(p.prec)) p.range_check = 1;
   int v = p.variant;
   if (v != TA_CV_AUTO) {
     if (!variant_eligible(v, p))

@@ -423,11 +423,9 @@ int ta_model_run_ops(ta_model* m) {
         }
         p.variant = op.variant & 255;
         if ((op.variant >> 16) & 1) p.bias9 = wptr(m, op.scale2_off);
-        p.wus = wptr(m, op.wus_off);
-        p.res_scale = 1.0f;                           // the packer gives a shortcut the exponents of the sum it joins
         // a tensor no op reads is a float32 RESULT (embeddings, detector heads): nothing splits it into half floats, whatever it holds
         p.range_check = (m->has_half_ops && (m->tensor_read[op.out] || (op.out2 >= 0 && m->tensor_read[op.out2]))) ? 1 : 0;
-        p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
+        p.amax_index = (m->amax_on && oi < TA_AMAX_OPS) ? (int)oi : -1;
         double flops = 2.0 * op.macs_per_pixel * (double)p.M;
         if (op.pool) {
           p.pool = 1;
@@ -464,11 +462,8 @@ int ta_model_run_ops(ta_model* m) {
         p.act = op.act;
         p.stride = 1;
         p.prec = op.prec;
-        p.wus = wptr(m, op.wus_off);
-        p.res_scale = 1.0f;
         p.range_check = (m->has_half_ops && m->tensor_read[op.out]) ? 1 : 0;
-        p.amax_slot = m->amax_dev ? m->amax_dev + 2 * oi : nullptr;
-        p.amax_mid_slot = m->amax_dev ? m->amax_dev + 2 * oi + 1 : nullptr;
+        p.amax_index = (m->amax_on && oi < TA_AMAX_OPS) ? (int)oi : -1;
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.c);
         p.in_row = ti.wp() * ti.c;
         p.in_pix = ti.c;
@@ -553,7 +548,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
     if (op.type == TA_OP_CONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
-            op.stride <= 0 || op.wus_off < 0 || bad_w(op.wus_off, (size_t)op.coutp * 4) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            op.stride <= 0 || op.wus_off != op.bias_off + 4 * (int64_t)op.coutp || bad_w(op.wus_off, (size_t)op.coutp * 4) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||
@@ -563,7 +558,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
       bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
     } else if (op.type == TA_OP_DWPW) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.scale2_off < 0 || op.shift2_off < 0 || op.cin % 4 || op.cout % 4 ||
-            (op.prec != 0 && op.prec != 3) || op.wus_off < 0 || bad_w(op.wus_off, (size_t)op.coutp * 4) ||
+            (op.prec != 0 && op.prec != 3) || op.wus_off != op.bias_off + 4 * (int64_t)op.coutp || bad_w(op.wus_off, (size_t)op.coutp * 4) ||
             op.coutp % 32 || op.n_slabs <= 0 || op.n_slabs * 32 < op.cin || (op.stride != 1 && op.stride != 2) ||
             bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) || bad_w(op.bias_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.cin * 36) || bad_w(op.shift2_off, (size_t)op.cin * 4);
@@ -658,21 +653,18 @@ int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity) {
   ta_enter(m ? m->ctx : nullptr);
   if (!m) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
-  const size_t n = 2 * m->ops.size();
+  const size_t n = 2 * std::min(m->ops.size(), (size_t)TA_AMAX_OPS);
+  unsigned* slots = (unsigned*)ctx->range_flag + TA_AMAX_SLOT0;      // one set per context: one model collects at a time
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (out) {
-    if (!m->amax_dev) return ta_fail(ctx, TA_E_INVALID, "debug_amax: not enabled");
-    if ((size_t)capacity < n) return ta_fail(ctx, TA_E_CAPACITY, "debug_amax: %zu floats needed", n);
-    TA_HIP(ctx, hipMemcpy(out, m->amax_dev, n * sizeof(float), hipMemcpyDeviceToHost));   // bit patterns of |x| ARE the floats
+    if (!m->amax_on) return ta_fail(ctx, TA_E_INVALID, "debug_amax: not enabled");
+    if ((size_t)capacity < 2 * m->ops.size()) return ta_fail(ctx, TA_E_CAPACITY, "debug_amax: %zu floats needed", 2 * m->ops.size());
+    memset(out, 0, 2 * m->ops.size() * sizeof(float));
+    TA_HIP(ctx, hipMemcpy(out, slots, n * sizeof(float), hipMemcpyDeviceToHost));   // bit patterns of |x| ARE the floats
   }
   if (enable == 2) return TA_OK;                 // read only: the collection goes on
-  if (enable) {
-    if (!m->amax_dev) TA_HIP(ctx, hipMalloc((void**)&m->amax_dev, n * sizeof(unsigned)));
-    TA_HIP(ctx, hipMemset(m->amax_dev, 0, n * sizeof(unsigned)));
-  } else if (m->amax_dev) {
-    (void)hipFree(m->amax_dev);
-    m->amax_dev = nullptr;
-  }
+  if (enable) TA_HIP(ctx, hipMemset(slots, 0, 2 * TA_AMAX_OPS * sizeof(unsigned)));
+  m->amax_on = enable != 0;
   return TA_OK;
 }
 
@@ -689,7 +681,6 @@ void ta_model_free(ta_model* m) {
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
   free_plans(m);
-  if (m->amax_dev) (void)hipFree(m->amax_dev);
   if (m->weights_dev) (void)hipFree(m->weights_dev);
   delete m;
 }

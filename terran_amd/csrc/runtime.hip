@@ -142,7 +142,8 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   }
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
-  if (hipMalloc((void**)&ctx->range_flag, sizeof(int)) != hipSuccess || hipMemset(ctx->range_flag, 0, sizeof(int)) != hipSuccess ||
+  const size_t flag_bytes = sizeof(int) * (TA_AMAX_SLOT0 + 2 * TA_AMAX_OPS);
+  if (hipMalloc((void**)&ctx->range_flag, flag_bytes) != hipSuccess || hipMemset(ctx->range_flag, 0, flag_bytes) != hipSuccess ||
       hipHostMalloc((void**)&ctx->range_flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
     if (ctx->range_flag) (void)hipFree(ctx->range_flag);
     (void)hipStreamDestroy(ctx->stream);

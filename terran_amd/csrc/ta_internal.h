@@ -149,7 +149,7 @@ struct ta_ctx {
   int64_t conv_counts[16] = {0};
   // f16x3: raised (device side) by a conv epilogue that met |x| > 65504 while writing a half-split tensor; copied to
   // the pinned host word behind the results of a call (ta_range_enqueue) and turned into TA_E_RANGE (ta_range_check)
-  int* range_flag = nullptr;
+  int* range_flag = nullptr;                       // device: [0] the flag, [TA_AMAX_SLOT0 ..] the tools' amax slots (2 per op, TA_AMAX_OPS ops)
   int* range_flag_host = nullptr;
   // algorithmic FLOPs per dense-conv KERNEL INSTANCE ("conv_igemm_split<2,4,4,3,3>", ...) since the last reset
   // (ta_debug_kernel_work): joins a rocprofv3 per-kernel time table with the work each template instance did
@@ -162,6 +162,8 @@ struct ta_ctx {
   }
 };
 void ta_pose_free_big(ta_ctx* ctx);  // frees pose_dbg.over
+#define TA_AMAX_SLOT0 16
+#define TA_AMAX_OPS 4096
 int ta_range_enqueue(ta_ctx* ctx);   // async copy of the flag on the context's stream (before the call's final sync)
 int ta_range_check(ta_ctx* ctx);     // after that sync: TA_OK, or TA_E_RANGE (and the flag is cleared for the next call)
 int ta_range_finish(ta_ctx* ctx, int rc);   // end of a task entry point: TA_E_RANGE takes precedence over the post-processing's own result
@@ -274,7 +276,6 @@ struct ta_conv_launch {
   const float* dw_w;                           // [9][dw_c]
   const float* dw_bias;                        // [dw_c]
   int dw_c, dw_stride;
-  unsigned* amax_mid_slot;                     // tools: the same for the depthwise intermediate of a dw+pw block
   // pool = 1 (split-role kernel only): tile pixels are ordered quad by quad -- pixel t of the launch is position
   // (t >> 1 & 1, t & 1) of 2x2 window t >> 2, windows in raster order over the POOLED map (Ho x Wo here are the pooled
   // sizes, M = 4 N Ho Wo) -- and the epilogue stores the max of every window instead of the four pixels
@@ -284,17 +285,18 @@ struct ta_conv_launch {
   float r_nct, r_tile_blocks, r_Wo, r_Ho, r_HoWo;
   int fast_div;                                // 1: every dividend of the set-up is < 2^24 (exact in float32)
   int fast_drain;                              // 1: the lean epilogue applies (split-format tensors below 4 GB, cout % 8 == 0, no pool / K-split)
-  int probe;                                   // tools only: 1 = producers skip the pixel-row DMA after the ring is full,
-                                               //             2 = no DMA at all after the ring is full (WRONG results)
+  int probe;                                   // tools only: bits 0..1: 1 = producers skip the pixel-row DMA after the ring is full,
+                                               //             2 = no DMA at all after the ring is full (WRONG results);
+                                               //             bit 2 (TA_CONV_LATE_B): slab 0's pixel-row DMAs after ALL addresses are computed
+                                               // [bias .. bias + coutp) is followed by the per-channel un-scale vector wus[coutp] (ta_op_desc.wus_off
+                                               // == bias_off + 4 coutp): one pointer for both keeps the kernel-argument block (SGPRs) small
   const float* bias9;                          // border-class biases [16][coutp] of a conv with a folded input affine (nullptr: none)
-  int late_b;                                  // tools only (TA_CONV_LATE_B): slab 0's pixel-row DMAs after ALL addresses are computed
-  const float* wus;                            // [coutp]: the sums of channel co are multiplied by wus[co] before the bias (ta_op_desc.wus_off)
-  float res_scale;                             // the shortcut is added times this (1: the packer gives a shortcut and the sum it joins the same
-                                               // per-channel exponents; the field stays for programs that do not)
-  int range_check;                             // 1: the program has half-float convs -- EVERY store of EVERY op is range-checked (a float32
-                                               // tensor written by an exact-f32 op may be split into half floats by its consumer)
+  int range_check;                             // 1: the program has half-float convs and some op reads this op's output -- every store is
+                                               // range-checked whatever the op's own mode (a float32 tensor written by an exact-f32 op
+                                               // may be split into half floats by its consumer)
+  int amax_index;                              // tools (ta_model_debug_amax): -1, or the op's slot pair behind the flag word: atomicMax of the
+                                               // bit pattern of the largest |x| stored (slot 2 i), of a dw+pw block's depthwise rows (2 i + 1)
   int* range_flag;                             // set to 1 by an epilogue that stores |x| > 65504, inf or NaN while range_check is on
-  unsigned* amax_slot;                         // tools (ta_model_debug_amax): atomicMax of the bit pattern of the largest |x| stored
 };
 
 // the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
@@ -361,7 +363,7 @@ struct ta_model {
   char* weights_dev = nullptr;
   bool has_half_ops = false;                    // any conv / dw+pw op with prec 3 / 4: every store is range-checked (ta_conv_launch::range_check)
   float* ones_dev = nullptr;                    // [max coutp] of 1.0f: the un-scale vector of ops packed without one
-  unsigned* amax_dev = nullptr;                 // tools (ta_model_debug_amax): [2 * n_ops] largest |x| bit patterns (output, dw intermediate)
+  bool amax_on = false;                         // tools (ta_model_debug_amax): ops report the largest |x| they store into the context's slots
   std::vector<char> tensor_read;                // per tensor: some op of the program reads it (results no op reads are not range-checked)
   std::vector<std::vector<float>> unscale_host; // per tensor: host copy of its un-scale vector (empty: none)
   std::vector<char> weights_host_small;         // host copy of the few weights that travel as kernel arguments (TA_OP_RFSTEM)

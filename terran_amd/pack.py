@@ -386,10 +386,14 @@ class Program:
             variant |= 1 << 16
         else:
             scale2_off, fold['scale2'] = vec(scale2)
-        bias_off, fold['bias'] = vec(bias if bias is not None else np.zeros(cout))
+        bvec = np.zeros(coutp, np.float64)
+        if bias is not None:
+            bvec[:cout] = np.asarray(bias, np.float64)
+        fold['bias'] = bvec
+        bias_off = self._w(np.concatenate([bvec, np.ones(coutp)]))       # [bias | per-channel un-scale]: one pointer for the kernels
+        wus_off = bias_off + 4 * coutp
         prelu_off, _ = vec(prelu)
         shift2_off, fold['shift2'] = vec(shift2)
-        wus_off, _ = vec(np.ones(cout), fill=1.0)
         op = dict(type=OP_CONV, out=tout, in_ch_off=in_ch_off, cin=cin_p, out_ch_off=out_ch_off, cout=cout_p,
                   coutp=coutp, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res=res, res_ch_off=res_ch_off,
                   res_up2=res_up2, out2=out2, out2_ch_off=out2_ch_off, n_slabs=n_slabs, prec=prec,
@@ -489,9 +493,11 @@ class Program:
         bd = np.asarray(bd, np.float64)
         op = dict(type=OP_DWPW, out=tout, in_ch_off=0, cin=C, out_ch_off=0, cout=cout, coutp=coutp, kh=1, kw=1,
                   stride=stride, pad=0, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0,
-                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w_reserve(n_slabs * coutp * 128), bias_off=self._w(bias), prelu_off=-1,
-                  scale2_off=self._w(w9), shift2_off=self._w(bd), wus_off=self._w(np.ones(coutp)),
+                  n_slabs=n_slabs, prec=prec, groups=1, variant=0, pool=0, wscale_log2=0, w_off=self._w_reserve(n_slabs * coutp * 128),
+                  bias_off=self._w(np.concatenate([bias, np.ones(coutp)])), prelu_off=-1,
+                  scale2_off=self._w(w9), shift2_off=self._w(bd), wus_off=-1,
                   macs_per_pixel=float(cout * C))
+        op['wus_off'] = op['bias_off'] + 4 * coutp
         op['in'] = tin
         # moments: depthwise (+ ReLU) -> the intermediate that is split into half floats in registers -> 1x1 (+ ReLU)
         st = self._stats_of(tin)
@@ -742,8 +748,7 @@ class Program:
                     f['rows64'] = rows
                 f['wexp'] = wexp
                 self._rewrite(op['w_off'], data, raw=True)
-                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32)))
-                self._rewrite(op['bias_off'], f['bias'] * up)
+                self._rewrite(op['bias_off'], np.concatenate([f['bias'] * up, np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32))]))
                 if 'bias9' in f:
                     self._rewrite(op['scale2_off'], f['bias9'] * up[None, :])
                 elif op['out2'] >= 0:
@@ -776,8 +781,7 @@ class Program:
                 if op['prec'] == 3:
                     packed, wexp = split_f16_rows(packed)
                 self._rewrite(op['w_off'], np.ascontiguousarray(packed, dtype=np.float32).tobytes(), raw=True)
-                self._rewrite(op['wus_off'], np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32)))
-                self._rewrite(op['bias_off'], f['bias'] * up)
+                self._rewrite(op['bias_off'], np.concatenate([f['bias'] * up, np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32))]))
             elif op['type'] == OP_RFSTEM:
                 parts = list(f['rfstem'])
                 parts[4] = (parts[4].reshape(16, 8) * up[:16, None]).ravel()

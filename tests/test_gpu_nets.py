@@ -258,6 +258,7 @@ def test_wild_statistics_nets_vs_reference_goldens(ctx, states, precision):
     (DESIGN section 4), held to 5e-3 here; its detector / pose programs are f16x3's."""
     from terran_amd import lib
     _prec[0] = 'f16x3' if precision == 'f16' else precision
+    wt = {'f32': 1e-4, 'f16x3': 1e-4, 'bf16x3': 4e-4}[_prec[0]]      # ill-conditioned weights: ~3 x the benign nets' distance, in every mode
     g = golden('wild_retinaface.npz')
     n, h, w = (int(v) for v in g['shape'])
     m = lib.Model(ctx, pack.pack_retinaface(states('wild_retinaface'), precision))
@@ -265,24 +266,24 @@ def test_wild_statistics_nets_vs_reference_goldens(ctx, states, precision):
     for i, s in enumerate((32, 16, 8)):
         head = m.read('head%d' % s)
         fg = 1.0 / (1.0 + np.exp(head[:, 0:2].astype(np.float64) - head[:, 2:4].astype(np.float64)))
-        _close(fg, g['out%d' % (3 * i)][:, 2:4], what='wild fg prob s%d' % s)
-        _close(head[:, 4:12], g['out%d' % (3 * i + 1)], what='wild bbox s%d' % s)
-        _close(head[:, 12:32], g['out%d' % (3 * i + 2)], what='wild lmk s%d' % s)
+        _close(fg, g['out%d' % (3 * i)][:, 2:4], tol=wt, what='wild fg prob s%d' % s)
+        _close(head[:, 4:12], g['out%d' % (3 * i + 1)], tol=wt, what='wild bbox s%d' % s)
+        _close(head[:, 12:32], g['out%d' % (3 * i + 2)], tol=wt, what='wild lmk s%d' % s)
     assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
     m.free()
     g = golden('wild_openpose.npz')
     n, h, w = (int(v) for v in g['shape'])
     m = lib.Model(ctx, pack.pack_openpose(states('wild_openpose'), precision))
     m.forward_frames(ctx.upload(synth.frames(int(g['frames_seed']), n, h, w)))
-    _close(m.read('pafs'), g['pafs'], what='wild golden pafs')
-    _close(m.read('heatmaps'), g['heatmaps'], what='wild golden heatmaps')
+    _close(m.read('pafs'), g['pafs'], tol=wt, what='wild golden pafs')
+    _close(m.read('heatmaps'), g['heatmaps'], tol=wt, what='wild golden heatmaps')
     assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
     m.free()
     g = golden('wild_arcface.npz')
     m = lib.Model(ctx, pack.pack_arcface(states('wild_arcface'), precision))
     m.forward_crops(g['crops'])
     out = m.read('embedding')[:, :, 0, 0]
-    _close(out, g['embeddings'], tol=2e-2 if precision == 'f16' else None, what='wild golden embedding')
+    _close(out, g['embeddings'], tol=2e-2 if precision == 'f16' else wt, what='wild golden embedding')
     unit = lambda e: e / np.sqrt((e.astype(np.float64) ** 2).sum(1, keepdims=True))
     err = float(np.abs(unit(out) - unit(g['embeddings'])).max())
     print('  wild arcface %s: unit embeddings max abs err %.2e' % (precision, err))
