@@ -986,6 +986,13 @@ def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
     workload, all host cores.  kind = "port": the reference's Python cannot travel to the GPU box."""
     import torch
     from oracle import pipeline
+    # this leg is the reference's CPU path on ALL host cores: undo the rank's NUMA binding (terran_amd/affinity.py) before torch
+    # builds its thread pool -- the pool's threads inherit the mask of the thread that creates them
+    if hasattr(os, 'sched_setaffinity'):
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except OSError:
+            pass
     n = len(frames_host)
     t0 = time.perf_counter()
     dets = pipeline.detection(sd_r, frames_host, short_side=416)
@@ -1001,7 +1008,8 @@ def cpu_baseline(frames_host, F, sd_r, sd_a, sd_p, fallback_lm):
     pipeline.estimation(sd_p, frames_host, short_side=184, bicubic_impl='torch')
     t3 = time.perf_counter()
     dt = t3 - t0
-    return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'cpus_allowed': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None, 'kind': 'port',
             'sample': '%d of the same 1080p frames through oracle.pipeline detection+recognition(top-%d)+estimation '
                       '(torch-CPU fp32, %.1f s)' % (n, F, dt),
             'stage_ms_per_frame': {'detection': round((t1 - t0) / n * 1e3, 1), 'recognition': round((t2 - t1) / n * 1e3, 1),

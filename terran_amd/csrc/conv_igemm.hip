@@ -1801,14 +1801,16 @@ static int launch_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   const int n_pt = (p.M + BM - 1) / BM;
   const int groups = ((n_pt + 7) / 8) * n_ct;
   const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float);
-  {
-    static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC);
-    ctx->note_kernel(name);
-  }
   // two instances: the usual one drains through LDS only; channel slices off the 8-channel boundaries (or the A/B switch
   // TA_CONV_DIRECT_EPILOGUE) take the one that also carries the direct epilogue -- and pays for it in registers
   const bool staged = ((p.out_ch | p.res_ch | p.o2_ch | p.direct_epilogue) & 7) == 0 && (p.cout & 3) == 0;
+  {
+    static char name[2][64];
+    if (!name[0][0])
+      for (int d = 0; d < 2; ++d)
+        snprintf(name[d], sizeof(name[d]), "conv_igemm<%d,%d,%d,%d,%d,%s>", WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, d ? "true" : "false");
+    ctx->note_kernel(name[staged ? 0 : 1]);
+  }
   if (staged) {
     auto kern = conv_igemm<WAVES_M, WAVES_N, WM_TILES, WN_TILES, PREC, false>;
     TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
