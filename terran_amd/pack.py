@@ -579,6 +579,10 @@ class Program:
                     k64 = op['cin'] % 64 == 0 and op['n_slabs'] == taps * (op['cin'] // 64)      # already re-packed by blob()
                     pipe = (pipe or (k64 and op['coutp'] % 64 == 0)) and \
                         op['cin'] % 64 == 0 and op['in_ch_off'] == 0 and op['groups'] == 1
+                # the kernels that read pre-split tensors drain through LDS only: every channel slice of the op on an 8-channel
+                # boundary (conv_igemm.hip: variant_eligible `staged`); anything else runs on the generic kernel, float32 in
+                if op['out_ch_off'] % 8 or op['res_ch_off'] % 8 or op['out2_ch_off'] % 8:
+                    pipe = False
                 if not pipe:
                     fmt[op['in']] = FMT_F32
             elif op['type'] in (OP_DWPW, OP_RFSTEM):            # float32 in, float32 out
