@@ -1,0 +1,119 @@
+"""Sample the GPU's power, shader clock and temperature (amdgpu sysfs / hwmon) while a command runs.
+
+    python tools/power_log.py --out gpurun_out/power.txt -- python bench.py --single-mode
+
+Evidence for DESIGN section 4's "the pipelined step is held by the power budget, not by issue slots": the socket power
+during the timed region against its cap, and the shader clock the chip holds there against the 2.4 GHz the peak figures
+are quoted at.  Reads whatever of these files the box has (none -> says so and just runs the command):
+  hwmon*/power1_average | power1_input (uW), power1_cap (uW), freq1_input (Hz, sclk), freq2_input (Hz, mclk),
+  temp*_input (m degC), and rocm-smi as a fallback for power / sclk when hwmon has none.
+"""
+import argparse
+import glob
+import os
+import subprocess
+import sys
+import threading
+import time
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def find_hwmon():
+    """hwmon directory of the first amdgpu device that has a power or clock file."""
+    for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+        if (_read(os.path.join(card, 'vendor')) or '').lower() != '0x1002':
+            continue
+        for h in sorted(glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))):
+            names = os.listdir(h)
+            if any(n.startswith(('power1_', 'freq1_')) for n in names):
+                return card, h
+    return None, None
+
+
+def sample(hw):
+    row = {}
+    for key, names in (('power_w', ('power1_average', 'power1_input')), ('cap_w', ('power1_cap',)),
+                       ('sclk_mhz', ('freq1_input',)), ('mclk_mhz', ('freq2_input',))):
+        for n in names:
+            v = _read(os.path.join(hw, n))
+            if v and v.lstrip('-').isdigit():
+                row[key] = int(v) / 1e6
+                break
+    temps = [int(v) / 1e3 for v in (_read(p) for p in glob.glob(os.path.join(hw, 'temp*_input'))) if v and v.isdigit()]
+    if temps:
+        row['temp_c'] = max(temps)
+    return row
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--period', type=float, default=0.05)
+    ap.add_argument('cmd', nargs=argparse.REMAINDER)
+    args = ap.parse_args()
+    cmd = args.cmd[1:] if args.cmd and args.cmd[0] == '--' else args.cmd
+    card, hw = find_hwmon()
+    rows = []
+    stop = threading.Event()
+
+    def loop():
+        t0 = time.perf_counter()
+        while not stop.is_set():
+            r = sample(hw)
+            r['t'] = time.perf_counter() - t0
+            rows.append(r)
+            stop.wait(args.period)
+
+    th = None
+    if hw:
+        th = threading.Thread(target=loop, daemon=True)
+        th.start()
+    rc = subprocess.call(cmd)
+    stop.set()
+    if th:
+        th.join()
+    lines = ['# %s' % ' '.join(cmd), '# device %s, hwmon %s, files: %s' % (card, hw, ' '.join(sorted(os.listdir(hw))) if hw else '-')]
+    if not hw:
+        lines.append('# no amdgpu hwmon files on this box: nothing sampled')
+    for key in ('power_w', 'sclk_mhz', 'mclk_mhz', 'temp_c'):
+        vals = [r[key] for r in rows if key in r]
+        if not vals:
+            continue
+        s = sorted(vals)
+        # "loaded" = samples in the upper half of the power range: the timed region, not import / packing / the CPU baseline
+        lines.append('%-9s n %5d  min %9.1f  median %9.1f  p90 %9.1f  max %9.1f' %
+                     (key, len(s), s[0], s[len(s) // 2], s[int(0.9 * (len(s) - 1))], s[-1]))
+    caps = [r['cap_w'] for r in rows if 'cap_w' in r]
+    if caps:
+        lines.append('cap_w     %.1f' % caps[0])
+    pw = [r.get('power_w') for r in rows]
+    if any(p is not None for p in pw):
+        hi = max(p for p in pw if p is not None)
+        lo = min(p for p in pw if p is not None)
+        loaded = [r for r in rows if r.get('power_w') is not None and r['power_w'] >= lo + 0.6 * (hi - lo)]
+        if loaded:
+            lines.append('# samples with power >= idle + 0.6 (max - idle): %d (%.1f s)' % (len(loaded), len(loaded) * args.period))
+            for key in ('power_w', 'sclk_mhz', 'temp_c'):
+                v = [r[key] for r in loaded if key in r]
+                if v:
+                    lines.append('loaded %-9s mean %9.1f  min %9.1f  max %9.1f' % (key, sum(v) / len(v), min(v), max(v)))
+    lines.append('# time series (every 4th sample): t_s power_w sclk_mhz temp_c')
+    for r in rows[::4]:
+        lines.append('%8.2f %8.1f %8.1f %6.1f' % (r['t'], r.get('power_w', float('nan')), r.get('sclk_mhz', float('nan')),
+                                                   r.get('temp_c', float('nan'))))
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    with open(args.out, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:14]), file=sys.stderr)
+    sys.exit(rc)
+
+
+if __name__ == '__main__':
+    main()
