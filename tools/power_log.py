@@ -25,10 +25,22 @@ def _read(path):
         return None
 
 
-def find_hwmon():
-    """hwmon directory of the first amdgpu device that has a power or clock file."""
+def hip_bus_id(device=0):
+    """PCI address of HIP device `device` as this process tree sees it (asked in a child: the sampler holds no GPU context)."""
+    code = ("import ctypes; h = ctypes.CDLL('libamdhip64.so'); b = ctypes.create_string_buffer(64); "
+            "rc = h.hipDeviceGetPCIBusId(b, 64, %d); print(b.value.decode() if rc == 0 else '')" % device)
+    try:
+        return subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120).stdout.strip().lower()
+    except Exception:
+        return ''
+
+
+def find_hwmon(bdf=''):
+    """hwmon directory of the amdgpu device at PCI address `bdf` (else of the first one that has a power or clock file)."""
     for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
         if (_read(os.path.join(card, 'vendor')) or '').lower() != '0x1002':
+            continue
+        if bdf and os.path.basename(os.path.realpath(card)).lower() != bdf:
             continue
         for h in sorted(glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))):
             names = os.listdir(h)
@@ -56,10 +68,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
     ap.add_argument('--period', type=float, default=0.05)
+    ap.add_argument('--device', type=int, default=0, help='HIP device index whose sensors to read')
     ap.add_argument('cmd', nargs=argparse.REMAINDER)
     args = ap.parse_args()
     cmd = args.cmd[1:] if args.cmd and args.cmd[0] == '--' else args.cmd
-    card, hw = find_hwmon()
+    bdf = hip_bus_id(args.device)
+    card, hw = find_hwmon(bdf)
     rows = []
     stop = threading.Event()
 
@@ -79,7 +93,7 @@ def main():
     stop.set()
     if th:
         th.join()
-    lines = ['# %s' % ' '.join(cmd), '# device %s, hwmon %s, files: %s' % (card, hw, ' '.join(sorted(os.listdir(hw))) if hw else '-')]
+    lines = ['# %s' % ' '.join(cmd), '# HIP device %d = pci %s -> %s, %s' % (args.device, bdf or '?', card, hw)]
     if not hw:
         lines.append('# no amdgpu hwmon files on this box: nothing sampled')
     for key in ('power_w', 'sclk_mhz', 'mclk_mhz', 'temp_c'):
