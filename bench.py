@@ -233,10 +233,11 @@ def run(args):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    from terran_amd import Detection, Recognition, Estimation, affinity, runtime, shard, video
+    from terran_amd import Detection, Recognition, Estimation, affinity, runtime, shard, telemetry, video
     # this rank's host threads (task threads, reader threads, the pinned staging they touch first) on the cores of the socket
     # its GPU hangs off: at 2 600 frames/s a rank moves 16 GB/s through pinned memory (terran_amd/affinity.py)
     placement = affinity.bind(device_index)
+    power_hw = telemetry.hwmon_of_pci(placement.get('pci'))
 
     # Host side: a pipeline of three host threads per GPU, each with its own context (HIP stream + scratch):
     # detection, embedding (fed the detections of its batch through a queue) and pose.  Kernels of the streams
@@ -484,6 +485,7 @@ def run(args):
             engine['resident'] = engine['sp'].scatter(frames_host)            # resident in HBM before timing
         if args.warmup:
             run_steps(args.warmup if not streaming else max(args.warmup, 2 * L))      # every lane warms its plans
+        sampler = telemetry.PowerSampler(power_hw).start()          # this rank's GPU: socket power / shader clock (sysfs)
         elapsed, out = timed(steps)
         res = {'elapsed_k': elapsed, 'steps_k': steps, 'elapsed': elapsed, 'steps': steps, 'out': out}
         # The chip clocks to its power budget: a region of a few tenths of a second reads ~8 % above what the same loop
@@ -492,8 +494,13 @@ def run(args):
         # the K-step region, so it is the same on every rank.
         if min_seconds > 0 and elapsed < min_seconds and not (args.serial or args.join_steps):
             k = int(np.ceil(min_seconds / (elapsed / steps)))
+            sampler.stop()
+            sampler = telemetry.PowerSampler(power_hw).start()
             e2, out = timed(k)
             res.update(elapsed=e2, steps=k, out=out)
+        sampler.stop()
+        # the sensor reports a moving average: the first 0.5 s of a region still hold what ran before it
+        res['power'] = sampler.summary(skip_seconds=min(0.5, 0.25 * res['elapsed']))
         res['klass'] = profile_serial_step()
         if extra:
             extra(res)
@@ -591,7 +598,7 @@ def run(args):
                 others[prec] = {'value': fps(r2['elapsed'], r2['steps']), 'steps': r2['steps'],
                                 'timed_region_s': round(r2['elapsed'], 3),
                                 'ms_per_step': round(r2['elapsed'] / r2['steps'] * 1e3, 3),
-                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm'])}
+                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm']), 'power': r2.get('power')}
 
     # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
     other_faces = {}
@@ -719,6 +726,7 @@ def run(args):
             result['value_f32'] = others['f32']['value']
             result['ms_per_step_f32'] = others['f32']['ms_per_step']
             result['roofline_f32'] = others['f32']['roofline']
+            result['power_f32'] = others['f32']['power']
         if 'f16x3' in others:                                        # every network float32-grade (embeddings to 5e-7)
             result['value_f16x3'] = others['f16x3']['value']
             result['ms_per_step_f16x3'] = others['f16x3']['ms_per_step']
@@ -727,6 +735,11 @@ def run(args):
             result['value_f16_embedder'] = others['f16']['value']
             result['ms_per_step_f16_embedder'] = others['f16']['ms_per_step']
             result['roofline_f16_embedder'] = others['f16']['roofline']
+        # rank 0's GPU over the region `value` comes from, driver-run: amdgpu hwmon power1_* / freq1_input every 50 ms.  In
+        # f16x3 the chip sits at its package power cap with the shader clock ~20 % under the 2.4 GHz the peak is quoted at
+        # (DESIGN.md section 4); null when the box exposes no sensors
+        result['power'] = dict(head['power'], what='socket power (W) / shader clock (MHz) / hottest sensor (C) of rank 0\'s GPU over the '
+                               'timed region, sysfs hwmon of its PCI function') if head.get('power') else None
         if 'ingest' in head:
             result['ingest'] = head['ingest']
         if c2_multi is not None:

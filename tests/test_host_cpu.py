@@ -511,3 +511,25 @@ def test_activation_scales_follow_the_expected_magnitudes():
     # ... up to 2^8 (pack._CH_SPREAD): beyond that the rest of the tensor follows (a channel's own bound is a noisy number)
     d = c.scales[1] - a.scales[1]
     assert d[5] == -12 and (np.delete(d, 5) == -(12 - pack._CH_SPREAD)).all()
+
+
+def test_power_sampler_reads_hwmon_files_and_is_a_noop_without_them(tmp_path):
+    """terran_amd.telemetry: bench.py's `power` object (socket power / shader clock over the timed region) comes from the amdgpu
+    hwmon files of the GPU's PCI function; a box without them (this container) yields None and never raises."""
+    import time
+    from terran_amd import telemetry
+    assert telemetry.hwmon_of_pci(None) is None and telemetry.hwmon_of_pci('0000:00:00.0') is None
+    idle = telemetry.PowerSampler(None).start()
+    assert idle.stop() == [] and idle.summary() is None
+    for name, v in (('power1_input', 1300000000), ('power1_cap', 1400000000), ('freq1_input', 1900000000),
+                    ('temp2_input', 55000), ('temp3_input', 61000)):
+        (tmp_path / name).write_text('%d\n' % v)
+    row = telemetry.sample(str(tmp_path))
+    assert row == {'power_w': 1300.0, 'cap_w': 1400.0, 'sclk_mhz': 1900.0, 'temp_c': 61.0}
+    s = telemetry.PowerSampler(str(tmp_path), 0.005).start()
+    time.sleep(0.06)
+    rows = s.stop()
+    assert len(rows) >= 3 and rows[0]['t'] <= rows[-1]['t']
+    summ = s.summary(skip_seconds=0.02)
+    assert summ['power_w_mean'] == 1300.0 and summ['cap_w'] == 1400.0 and summ['sclk_mhz_min'] == 1900.0
+    assert summ['samples'] < len(rows)

@@ -9,20 +9,13 @@ are quoted at.  Reads whatever of these files the box has (none -> says so and j
   temp*_input (m degC), and rocm-smi as a fallback for power / sclk when hwmon has none.
 """
 import argparse
-import glob
 import os
 import subprocess
 import sys
-import threading
-import time
 
 
-def _read(path):
-    try:
-        with open(path) as f:
-            return f.read().strip()
-    except OSError:
-        return None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from terran_amd import telemetry   # noqa: E402
 
 
 def hip_bus_id(device=0):
@@ -35,35 +28,6 @@ def hip_bus_id(device=0):
         return ''
 
 
-def find_hwmon(bdf=''):
-    """hwmon directory of the amdgpu device at PCI address `bdf` (else of the first one that has a power or clock file)."""
-    for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
-        if (_read(os.path.join(card, 'vendor')) or '').lower() != '0x1002':
-            continue
-        if bdf and os.path.basename(os.path.realpath(card)).lower() != bdf:
-            continue
-        for h in sorted(glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))):
-            names = os.listdir(h)
-            if any(n.startswith(('power1_', 'freq1_')) for n in names):
-                return card, h
-    return None, None
-
-
-def sample(hw):
-    row = {}
-    for key, names in (('power_w', ('power1_average', 'power1_input')), ('cap_w', ('power1_cap',)),
-                       ('sclk_mhz', ('freq1_input',)), ('mclk_mhz', ('freq2_input',))):
-        for n in names:
-            v = _read(os.path.join(hw, n))
-            if v and v.lstrip('-').isdigit():
-                row[key] = int(v) / 1e6
-                break
-    temps = [int(v) / 1e3 for v in (_read(p) for p in glob.glob(os.path.join(hw, 'temp*_input'))) if v and v.isdigit()]
-    if temps:
-        row['temp_c'] = max(temps)
-    return row
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
@@ -73,26 +37,11 @@ def main():
     args = ap.parse_args()
     cmd = args.cmd[1:] if args.cmd and args.cmd[0] == '--' else args.cmd
     bdf = hip_bus_id(args.device)
-    card, hw = find_hwmon(bdf)
-    rows = []
-    stop = threading.Event()
-
-    def loop():
-        t0 = time.perf_counter()
-        while not stop.is_set():
-            r = sample(hw)
-            r['t'] = time.perf_counter() - t0
-            rows.append(r)
-            stop.wait(args.period)
-
-    th = None
-    if hw:
-        th = threading.Thread(target=loop, daemon=True)
-        th.start()
+    hw = telemetry.hwmon_of_pci(bdf)
+    card = '/sys/bus/pci/devices/%s' % bdf if hw else None
+    sampler = telemetry.PowerSampler(hw, args.period).start()
     rc = subprocess.call(cmd)
-    stop.set()
-    if th:
-        th.join()
+    rows = sampler.stop()
     lines = ['# %s' % ' '.join(cmd), '# HIP device %d = pci %s -> %s, %s' % (args.device, bdf or '?', card, hw)]
     if not hw:
         lines.append('# no amdgpu hwmon files on this box: nothing sampled')
