@@ -94,6 +94,11 @@ class RangeFallback:
                 if e.code != lib.E_RANGE:
                     raise
         if self._fb_model is None:
+            import warnings
+            warnings.warn('terran_amd: %s activations left the half-float range of the split-half mode (TA_E_RANGE); this batch '
+                          'is re-run on an exact-f32 copy of the model (about 3x slower; after three such batches in a row it '
+                          'takes over).  precision="f32" avoids the first attempt; tools/amax_debug.py shows the layer.'
+                          % self._fb_kind, RuntimeWarning, stacklevel=3)
             self._fb_model = lib.Model(self.ctx, packed_program(self._fb_kind, self._fb_state, 'f32'))
         self.fallbacks += 1
         return fn(self._fb_model)

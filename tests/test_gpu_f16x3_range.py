@@ -199,7 +199,8 @@ def test_openpose_wrapper_falls_back_to_f32(states, monkeypatch):
     assert s.fallbacks == 0 and b.fallbacks == 0
     _no_scales(monkeypatch)
     a = OpenPose(device=0, short_side=96, state=sd, precision='f16x3')
-    ra = a.call(frames)
+    with pytest.warns(RuntimeWarning, match='TA_E_RANGE'):           # the first fallback of a model is announced
+        ra = a.call(frames)
     assert a.fallbacks == 1
     for r in (ra, rs):
         assert [len(p) for p in r] == [len(p) for p in rb] and sum(len(p) for p in r) >= 3
