@@ -121,6 +121,10 @@ int ta_model_read_tensor(ta_model* m, int tensor, int ch_off, int ch, float* dst
  * number of ops (TA_E_CAPACITY otherwise).  enable == 2 only reads (the collection goes on), enable == 0 ends it. */
 int ta_model_tensor_unscale(const ta_model* m, int tensor, float* out, int capacity);
 int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity);
+/* tools (tools/graph_probe.py): replays the op program of the last forward `reps` times as stream launches and as a hipGraph
+ * captured from them.  out_ms[5]: GPU ms per replay (streams, graph), host enqueue ms per replay (streams, graph), capture +
+ * instantiate ms.  Measurement aid for DESIGN.md section 4 ("why the programs are not hipGraphs"); no product path calls it. */
+int ta_model_graph_probe(ta_model* m, int reps, double* out_ms);
 
 /* ---- RetinaFace.call (retinaface/wrapper.py:133-238) ------------------------------------ */
 /* frames: (N,H,W,3) uint8 RGB at network resolution.  Per image: threshold (>=), sort by

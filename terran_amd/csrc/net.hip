@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "act_format.h"
 #include "ta_internal.h"
@@ -646,6 +647,57 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (m->ops[0].type == TA_OP_RFSTEM)
     m->weights_host_small.assign((const char*)blob + h.weights_off + m->ops[0].w_off, (const char*)blob + h.weights_off + m->ops[0].w_off + 448 * 4);
   *out = m;
+  return TA_OK;
+}
+
+// tools (tools/graph_probe.py): the op program of the LAST forward (same plan, same input) replayed `reps` times as plain stream
+// launches and as a hipGraph captured from them (lanes = fork / join through events: part of the capture).
+// out_ms[0] / [1]: GPU time per replay, streams / graph (HIP events on the main stream); out_ms[2] / [3]: host time the
+// enqueue of one replay takes, streams / graph; out_ms[4]: capture + instantiate, once.
+int ta_model_graph_probe(ta_model* m, int reps, double* out_ms) {
+  ta_enter(m ? m->ctx : nullptr);
+  if (!m || !out_ms || reps < 1) return TA_E_INVALID;
+  ta_ctx* ctx = m->ctx;
+  if (m->run_n <= 0) return ta_fail(ctx, TA_E_INVALID, "graph_probe: run a forward first (it replays that plan)");
+  hipEvent_t e0, e1;
+  TA_HIP(ctx, hipEventCreate(&e0));
+  TA_HIP(ctx, hipEventCreate(&e1));
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int i = 0; i < 2; ++i) TA_TRY(ta_model_run_ops(m));          // lazy state (function attributes, side streams) exists
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  double t0 = now();
+  TA_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i) TA_TRY(ta_model_run_ops(m));
+  TA_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  out_ms[2] = (now() - t0) / reps;
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TA_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  out_ms[0] = ms / reps;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  t0 = now();
+  TA_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  const int rc = ta_model_run_ops(m);
+  const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != TA_OK) return rc;
+  TA_HIP(ctx, ce);
+  TA_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  out_ms[4] = now() - t0;
+  for (int i = 0; i < 2; ++i) TA_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t0 = now();
+  TA_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i) TA_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+  TA_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  out_ms[3] = (now() - t0) / reps;
+  TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TA_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  out_ms[1] = ms / reps;
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return TA_OK;
 }
 

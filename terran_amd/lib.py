@@ -58,6 +58,7 @@ SIGNATURES = {
     'ta_model_tensor_shape': (c_int, [c_void_p, c_int, P(c_int), P(c_int), P(c_int), P(c_int)]),
     'ta_model_tensor_unscale': (c_int, [c_void_p, c_int, c_void_p, c_int]),
     'ta_model_debug_amax': (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    'ta_model_graph_probe': (c_int, [c_void_p, c_int, c_void_p]),
     'ta_model_read_tensor': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'ta_retinaface_run': (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, P(C.c_int32)]),
@@ -375,6 +376,12 @@ class Model:
     def amax_collect(self, on=True):
         """Start (zeroed) / stop collecting the largest |x| every conv / dw+pw op stores (ta_model_debug_amax)."""
         self.ctx.check(self.ctx.lib.ta_model_debug_amax(self.h, int(bool(on)), None, 0))
+
+    def graph_probe(self, reps=20):
+        """Tools: (gpu_ms_streams, gpu_ms_graph, host_ms_streams, host_ms_graph, capture_ms) of the last forward's op program."""
+        out = np.zeros(5, np.float64)
+        self.ctx.check(self.ctx.lib.ta_model_graph_probe(self.h, int(reps), ptr(out)))
+        return tuple(float(x) for x in out)
 
     def amax_read(self, n_ops):
         """-> (n_ops, 2) float32 in STORED units: [:, 0] op outputs, [:, 1] depthwise intermediates of dw+pw ops; the
