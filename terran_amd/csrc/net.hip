@@ -659,7 +659,21 @@ int ta_model_graph_probe(ta_model* m, int reps, double* out_ms) {
   if (!m || !out_ms || reps < 1) return TA_E_INVALID;
   ta_ctx* ctx = m->ctx;
   if (m->run_n <= 0) return ta_fail(ctx, TA_E_INVALID, "graph_probe: run a forward first (it replays that plan)");
-  hipEvent_t e0, e1;
+  struct res_t {                                      // released on every return path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~res_t() {
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } r;
+  hipEvent_t& e0 = r.e0;
+  hipEvent_t& e1 = r.e1;
+  hipGraph_t& graph = r.graph;
+  hipGraphExec_t& exec = r.exec;
   TA_HIP(ctx, hipEventCreate(&e0));
   TA_HIP(ctx, hipEventCreate(&e1));
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -674,8 +688,6 @@ int ta_model_graph_probe(ta_model* m, int reps, double* out_ms) {
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TA_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
   out_ms[0] = ms / reps;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
   t0 = now();
   TA_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
   const int rc = ta_model_run_ops(m);
@@ -694,10 +706,6 @@ int ta_model_graph_probe(ta_model* m, int reps, double* out_ms) {
   TA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TA_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
   out_ms[1] = ms / reps;
-  (void)hipGraphExecDestroy(exec);
-  (void)hipGraphDestroy(graph);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return TA_OK;
 }
 
