@@ -738,6 +738,13 @@ def run(args):
         # rank 0's GPU over the region `value` comes from, driver-run: amdgpu hwmon power1_* / freq1_input every 50 ms.  In
         # f16x3 the chip sits at its package power cap with the shader clock ~20 % under the 2.4 GHz the peak is quoted at
         # (DESIGN.md section 4); null when the box exposes no sensors
+        if head.get('power') and head['power'].get('sclk_mhz_mean'):
+            # the peak in `roofline.peak` is quoted at 2400 MHz; under its power cap the chip holds less: the same pipelined
+            # figure against the peak AT THE CLOCK IT RAN AT (informative; `frac` stays against the nominal peak)
+            held = head['power']['sclk_mhz_mean']
+            result['roofline']['held_clock_mhz'] = held
+            result['roofline']['pipelined_frac_at_held_clock'] = round(
+                result['roofline']['pipelined_achieved'] / (PEAKS[primary][0] * held / 2400.0), 4)
         result['power'] = dict(head['power'], what='socket power (W) / shader clock (MHz) / hottest sensor (C) of rank 0\'s GPU over the '
                                'timed region, sysfs hwmon of its PCI function') if head.get('power') else None
         if 'ingest' in head:

@@ -24,6 +24,9 @@ pytestmark = pytest.mark.gpu
 MODES = [m for m in ('f32', 'f16x3', 'bf16x3', 'f16') if m in pack.PRECISIONS]      # 'f16': the opt-in mode; its detector / pose programs are f16x3's
 HEADLINE = 'f16x3' if 'f16x3' in pack.PRECISIONS else 'bf16x3'
 N_SMALL, N_WORK, BATCH = 208, 16, 16
+# a longer count for profiles/ (the suite keeps the sizes above): TA_DECISIONS_SCALE=5 -> 1040 + 80 frames per task
+_SCALE = max(1, int(os.environ.get('TA_DECISIONS_SCALE', '1')))
+N_SMALL, N_WORK = N_SMALL * _SCALE, N_WORK * _SCALE
 _results = {}
 
 
