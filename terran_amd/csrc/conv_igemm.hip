@@ -313,6 +313,7 @@ __device__ __forceinline__ void conv_finish_sym(const ta_conv_launch& p, f32x16 
     }
   }
   __syncthreads();                                  // every wave is done reading operand fragments: the ring is free
+  if (tid == 0) TA_STAMP(21);
 #pragma unroll
   for (int b = 0; b < WN_TILES; ++b) {
     const int row = (wn * WN_TILES + b) * 32 + (lane & 31);
@@ -326,6 +327,7 @@ __device__ __forceinline__ void conv_finish_sym(const ta_conv_launch& p, f32x16 
       }
   }
   __syncthreads();
+  if (tid == 0) TA_STAMP(22);                       // tile parked
   conv_epilogue_drain<BN, BM, 256>(p, lds, ct0, pt0, tid, HoWo, 0);
 }
 
@@ -848,6 +850,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   const int ct0 = ct * BN;
   const int pt0 = pt * BM;
   const int HoWo = p.Ho * p.Wo;
+  if (wave == 0) TA_STAMP(16);                      // (debug build) entry
 
   // weight rows: DMA, lane -> (row = t*8 + lane/8, physical chunk lane%8), logical chunk = pchunk ^ ((row>>1)&7)
   const int pchunk = lane & 7;
@@ -934,14 +937,18 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   const int b_row0 = BN + wn * WN_TILES * 32 + frow;
 
   const int S = p.n_slabs;
+  if (wave == 0) TA_STAMP(17);                      // pixel addresses ready
   produce(0, 0);
+  if (wave == 0) TA_STAMP(18);                      // slab 0: taps loaded, depthwise rows written (weight DMA in flight)
   for (int s = 0; s < S; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // slab s (weights landed, pixel rows written); everyone is done reading the other stage
+    if (s == 0 && wave == 0) TA_STAMP(19);          // past the first barrier
     if (s + 1 < S) produce(s + 1, (s + 1) & 1);
     const float* st = lds + (s & 1) * STAGE;
     conv_slab_mma<WM_TILES, WN_TILES, PREC>(st, acc, a_row0, b_row0, fsw, fcb, lane);
   }
+  if (wave == 0) TA_STAMP(20);                      // MFMAs issued
   if constexpr (PREC != PREC_F32) {
     if (dw_amax > TA_F16_MAX_BITS) *p.range_flag = 1;
     if (p.amax_index >= 0) {
@@ -951,6 +958,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
     }
   }
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
+  if (wave == 0) TA_STAMP(23);                      // drained: stores issued
 }
 
 // t / d for a launch-uniform divisor whose float32 reciprocal the launcher supplied: one multiply and a +-1 fix-up
