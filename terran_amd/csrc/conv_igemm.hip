@@ -905,10 +905,14 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            // tools (TA_DWPW_PROBE, timing only, wrong results): 1 = every tap reads the window's first pixel (one line per
-            // pixel instead of nine), 2 = no tap loads at all -- what the block costs beyond its input traffic
+#ifdef TA_CONV_TRACE
+            // debug build only (TA_DWPW_PROBE, timing ablations, wrong results): 1 = every tap reads the window's first pixel
+            // (one line per pixel instead of nine), 2 = no tap loads at all -- what the block costs beyond its input traffic
             const size_t toff = (p.probe & 3) == 1 ? 0 : (size_t)ky * p.in_row + (size_t)kx * p.in_pix;
             v[ky * 3 + kx] = (p.probe & 3) == 2 ? bias : *(const f32x4*)(src[j] + toff + ch);
+#else
+            v[ky * 3 + kx] = *(const f32x4*)(src[j] + (size_t)ky * p.in_row + (size_t)kx * p.in_pix + ch);
+#endif
           }
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -1886,8 +1890,10 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
     return ta_fail(ctx, TA_E_INVALID, "dw+pw: needs the f32 or f16x3 mode, float32 input activations and 4-aligned channels");
   ta_prof_scope scope(ctx, 0, flops);
   ctx->cur_flops = flops;
-  static const int dw_probe = getenv("TA_DWPW_PROBE") ? atoi(getenv("TA_DWPW_PROBE")) & 3 : 0;   // tools: timing ablations
+#ifdef TA_CONV_TRACE
+  static const int dw_probe = getenv("TA_DWPW_PROBE") ? atoi(getenv("TA_DWPW_PROBE")) & 3 : 0;   // debug build: timing ablations
   p.probe = dw_probe;
+#endif
   if (p.prec == PREC_F16X3) {
     if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
     if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F16X3>(ctx, p);
