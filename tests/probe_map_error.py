@@ -1,9 +1,9 @@
 """RMS / max error of the pose network's output maps against a FLOAT64 evaluation, per arithmetic mode (GPU box).
 
-    python tools/map_error.py [wild|benign] [frames]
+    python tests/probe_map_error.py [wild|benign] [frames]
 Where the decision flips of tests/test_gpu_decisions_vs_oracle.py come from: how far each device mode's PAF / heat maps
 (and the torch-CPU float32 oracle's) are from the float64 maps, relative to the maps' RMS.  Pack-time knobs can be
-varied through the environment for experiments: TA_CH_SPREAD, TA_ACT_TARGET_LOG2 (terran_amd/pack.py)."""
+varied through the environment for experiments (a probe under tests/: it calls the oracle, which only tests may): TA_CH_SPREAD, TA_ACT_TARGET_LOG2 (terran_amd/pack.py)."""
 import os
 import sys
 

@@ -395,6 +395,6 @@ def test_wild_weights_decisions_vs_float64(states):
         assert head['range_fallbacks'] == 0 and f32['range_fallbacks'] == 0, rows
         assert f32['flips'] <= f32['decisions'] // 100 and orc['flips'] <= orc['decisions'] // 100, rows
         # counts of rare events on near-ties: the exact-f32 mode's own count with half of it and two standard deviations of
-        # slack (5 x the frames: detector 178 vs 194, pose 329 vs 256 -- connection flips come in clusters; tools/map_error.py: the maps
+        # slack (5 x the frames: detector 178 vs 194, pose 329 vs 256 -- connection flips come in clusters; tests/probe_map_error.py: the maps
         # themselves are as close to float64 in f16x3 as in f32)
         assert head['flips'] <= rare_bound(f32['flips']), rows
