@@ -86,9 +86,9 @@ class PowerSampler:
     def stop(self):
         if self._thread:
             self._stop.set()
-            self._thread.join()
+            self._thread.join(timeout=2.0)          # a sensor read that hangs must not hang the caller (daemon thread)
             self._thread = None
-        return self.rows
+        return list(self.rows)
 
     def summary(self, skip_seconds=0.0):
         """Means over the samples taken at least `skip_seconds` after start (the sensor averages over a window of its
