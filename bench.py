@@ -60,22 +60,27 @@ PEAKS = {
     'bf16x3': (2500.0, 'v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi, f32 accumulate)', 3),
     'bf16': (2500.0, 'v_mfma_f32_32x32x16_bf16', 1),
     'f16': (2500.0, 'v_mfma_f32_32x32x16_f16: x3 (split-half operands) in the detector and the pose network, x1 in the embedder', 3),
+    'f16x2': (2500.0, 'v_mfma_f32_32x32x16_f16: x3 (split-half operands) in the detector and the pose network, x2 in the embedder ((w_hi + w_lo) * x_hi)', 3),
 }
 HBM_PEAK_GBPS = 8000.0
 # The mode `value` is measured in = the LIBRARY DEFAULT (runtime.resolve_precision): every network on the float32-grade split-half
 # arithmetic (x = hi + lo, 22 significant bits, three f16 MFMAs per product; 0 decision flips vs the oracle, embeddings to 5e-7).
 # Beside it in the same line: `value_f16_embedder` (the opt-in tolerance mode: the embedder alone on one f16 MFMA per product,
 # embeddings 3.6e-4 against north_star's 1e-3 bar) and `value_f32` (every conv on the exact-f32 MFMA).
-HEADLINE = 'f16x3'
+HEADLINE = 'f16x2'
 DTYPES = {'f32': 'f32',
-          'f16x3': 'f16x3 (ArcFace / OpenPose operands x = hi + lo as two IEEE half floats = 22 significant bits, weights '
-                   'pre-scaled by a power of two per layer; 3 f16 MFMAs per product term (every product exact), f32 '
+          'f16x3': 'f16x3 (ArcFace / OpenPose operands x = hi + lo as two IEEE half floats = 22 significant bits, weight rows '
+                   'scaled by a power of two per OUTPUT CHANNEL, stored activations by one per channel; 3 f16 MFMAs per product term (every product exact), f32 '
                    'accumulate; the detector RetinaFace: refiner + deep base the same, the raw-pixel front exact f32) -- float32-grade: 0 decision flips vs '
                    'the oracle over 224 frames per task where the exact-f32 mode has 2 (profiles/r03_decisions_vs_oracle.txt)',
           'bf16x3': 'bf16x3 (ArcFace / OpenPose operands x = hi + lo as two bf16, ~16 mantissa bits; 3 bf16 MFMAs per '
                     'product term, f32 accumulate; the detector RetinaFace runs on the exact-f32 MFMA) -- passes the '
                     'same 1e-3 / bit-exact parity suite as f32',
           'bf16': 'bf16 (f32 accumulate)',
+          'f16x2': 'f16x3 for the detector and the pose network (every discrete decision at float32 grade, as in the f16x3 mode); the embedder '
+                   'ArcFace -- no decisions, north_star bar 1e-3 on the unit-norm embedding -- on TWO of the three products, (w_hi + w_lo) * x_hi: '
+                   'weights and the shortcut trunk keep 22 bits, every activation enters a contraction as its hi half (11 bits): 1.8e-4 worst '
+                   'embedding component vs the oracle on the seeded weights, 8.2e-4 on the wild-statistics weights (tests/probe_embedder_modes.py)',
           'f16': 'f16x3 for the detector and the pose network (every discrete decision at float32 grade, as in the f16x3 mode); the '
                  'embedder ArcFace -- no decisions, north_star bar 1e-3 on the unit-norm embedding -- with ONE f16 MFMA per product '
                  'on 2-byte half-float activations: 3.6e-4 worst embedding component vs the oracle (tolerance mode for that one task)'}
@@ -97,8 +102,8 @@ def conv_roofline(precision, conv):
         'launches_per_step': conv['launches'],
         'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
         'algorithmic_gflop_per_step': round(conv['work'] / 1e9, 1),
-        'mfma_flops_per_algorithmic_flop': factor if precision != 'f16' else '3 (detector, pose) / 1 (embedder)',
-        'mfma_issue_frac': round(achieved * factor / peak, 4) if precision != 'f16' else None,
+        'mfma_flops_per_algorithmic_flop': factor if precision not in ('f16', 'f16x2') else '3 (detector, pose) / %d (embedder)' % (1 if precision == 'f16' else 2),
+        'mfma_issue_frac': round(achieved * factor / peak, 4) if precision not in ('f16', 'f16x2') else None,
         'source': 'driver-run: HIP events around every conv launch of one serial step of this very process',
     }
     # The fields below are NOT measured by this run: they replay the builder's rocprofv3 --pmc passes of the same
@@ -110,7 +115,7 @@ def conv_roofline(precision, conv):
                                'per conv launch)' % precision)
     pm = os.path.join(REPO, 'profiles', 'pmc_mfma.json')
     if os.path.exists(pm):
-        c = json.load(open(pm)).get('f16x3' if precision == 'f16' else precision)      # f16: the dominant layers are the pose network's, on f16x3
+        c = json.load(open(pm)).get('f16x3' if precision in ('f16', 'f16x2') else precision)      # f16: the dominant layers are the pose network's, on f16x3
         if c:
             r['pmc_dominant_layers'] = dict(c, source='builder-run: profiles/pmc_mfma.json (tools/clock_probe.sh)')
     return r
@@ -149,10 +154,12 @@ def main():
     ap.add_argument('--faces', type=int, default=2, help='faces embedded per frame (top-F detections)')
     ap.add_argument('--cpu-frames', type=int, default=16, help='frames in the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3', 'bf16x3', 'bf16', 'f16'],
+    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3', 'bf16x3', 'bf16', 'f16', 'f16x2'],
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or f16x3)')
     ap.add_argument('--single-mode', action='store_true',
                     help='headline measurement only (no f32 / faces-per-frame / sustained / ingest / per-model legs)')
+    ap.add_argument('--no-side-legs', action='store_true',
+                    help='headline + ingest legs only (no other precisions / faces per frame / random-weights / per-model legs): multi-rank rehearsals')
     ap.add_argument('--inflight', type=int, default=4, help='lanes per GPU: batches in flight, each on its own upload / detect / embed / pose streams')
     ap.add_argument('--serial', action='store_true',
                     help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
@@ -175,6 +182,7 @@ def main():
                     help='--gpus N devices driven by ONE process through the facades\' device-list fan-out')
     ap.add_argument('--devices', default=None, help='with --single-process: comma-separated device ids (repeats allowed)')
     args = ap.parse_args()
+    args.side = not (args.single_mode or args.no_side_legs)
 
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')     # before torch initialises HIP: see terran_amd/lib.py:load
     # stdout carries exactly ONE line (the JSON): everything libraries print to fd 1 (RCCL's version banner, for
@@ -252,6 +260,8 @@ def run(args):
     # another thread's result handling before it can queue its next launch
     sys.setswitchinterval(float(os.environ.get('TA_BENCH_SWITCH', '2e-4')))
     (sd_r, sd_a, sd_p), frames_host, fallback_lm = make_workload(args, rank)
+    # what the pose network and the frames ARE can be swapped per leg (`value_random_pose_weights`): `work` holds the current pair
+    work = {'sd_p': sd_p, 'frames': frames_host}
     F = args.faces
     face_state = {'F': F}                                               # pick_faces reads the current faces-per-frame
     L = max(1, args.inflight)
@@ -272,14 +282,20 @@ def run(args):
         def __init__(self, first):
             self.ctxs = [runtime.get_context(device_index) if first else runtime.new_context(device_index),
                          runtime.new_context(device_index), runtime.new_context(device_index)]
-            self.frames = [c.upload(frames_host) for c in self.ctxs]      # resident in HBM before timing
+            self.frames = [c.upload(work['frames']) for c in self.ctxs]      # resident in HBM before timing
+            self.frames_of = work['frames']
             self.det = self.rec = self.est = None
 
         def load(self, precision):
             c_det, c_rec, c_pose = self.ctxs
+            if self.frames_of is not work['frames']:                      # a leg on other frames
+                for f in self.frames:
+                    f.free()
+                self.frames = [c.upload(work['frames']) for c in self.ctxs]
+                self.frames_of = work['frames']
             self.det = Detection(short_side=416, device=device_index, state=sd_r, ctx=c_det, precision=precision)
             self.rec = Recognition(device=device_index, state=sd_a, ctx=c_rec, precision=precision)
-            self.est = Estimation(short_side=184, device=device_index, state=sd_p, ctx=c_pose, precision=precision)
+            self.est = Estimation(short_side=184, device=device_index, state=work['sd_p'], ctx=c_pose, precision=precision)
 
         def unload(self):
             for m in (self.det.model, self.rec.model, self.est.model):
@@ -481,13 +497,16 @@ def run(args):
                                           embed_max_crops=args.embed_max_crops, embed_max_wait=args.embed_max_wait,
                                           detection_kw=dict(short_side=416, state=sd_r, precision=precision),
                                           recognition_kw=dict(state=sd_a, precision=precision),
-                                          estimation_kw=dict(short_side=184, state=sd_p, precision=precision))
-            engine['resident'] = engine['sp'].scatter(frames_host)            # resident in HBM before timing
+                                          estimation_kw=dict(short_side=184, state=work['sd_p'], precision=precision))
+            engine['resident'] = engine['sp'].scatter(work['frames'])            # resident in HBM before timing
         if args.warmup:
             run_steps(args.warmup if not streaming else max(args.warmup, 2 * L))      # every lane warms its plans
         sampler = telemetry.PowerSampler(power_hw).start()          # this rank's GPU: socket power / shader clock (sysfs)
+        cpu0 = time.process_time()
         elapsed, out = timed(steps)
         res = {'elapsed_k': elapsed, 'steps_k': steps, 'elapsed': elapsed, 'steps': steps, 'out': out}
+        # host side of this rank over the K-step region: CPU-seconds of the whole process (all lanes' threads) per step, live threads
+        res['host'] = {'cpu_s_per_step': round((time.process_time() - cpu0) / steps, 5), 'threads': threading.active_count()}
         # The chip clocks to its power budget: a region of a few tenths of a second reads ~8 % above what the same loop
         # sustains.  Every figure of the line therefore comes from a region of >= `min_seconds`; the exact-K region the
         # driver asked for is reported beside it (`value_k_steps`).  The step count follows from the max-over-ranks time of
@@ -496,8 +515,10 @@ def run(args):
             k = int(np.ceil(min_seconds / (elapsed / steps)))
             sampler.stop()
             sampler = telemetry.PowerSampler(power_hw).start()
+            cpu0 = time.process_time()
             e2, out = timed(k)
             res.update(elapsed=e2, steps=k, out=out)
+            res['host'] = {'cpu_s_per_step': round((time.process_time() - cpu0) / k, 5), 'threads': threading.active_count()}
         sampler.stop()
         # the sensor reports a moving average: the first 0.5 s of a region still hold what ran before it
         res['power'] = sampler.summary(skip_seconds=min(0.5, 0.25 * res['elapsed']))
@@ -568,7 +589,9 @@ def run(args):
             sync()
             t0 = time.perf_counter()
             run_steps(k, readers=readers, on_step=on_step)
+            tg = time.perf_counter()
             gather_all()
+            gather_s = time.perf_counter() - tg
             sync()
             e = time.perf_counter() - t0
             if use_dist:
@@ -582,6 +605,7 @@ def run(args):
             'value': fps(e, k), 'unit': 'frames/s', 'steps': k, 'ms_per_step': round(e / k * 1e3, 3),
             'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
             'steps_gathered_on_rank0': n_on_rank0[0],
+            'gather_s': round(gather_s, 4),                # the ONE ordered gather of the region's results on rank 0 (this rank's wait included)
             'what': 'same workload, every batch read from a raw rgb24 byte stream in host memory into pinned buffers and '
                     'uploaded by video.RawVideoReader (one reader thread + upload stream per pipeline, overlapped with '
                     'compute), the per-step results of all ranks gathered on rank 0 inside the timed region; stream reads are single-thread host memcpys '
@@ -589,20 +613,69 @@ def run(args):
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or HEADLINE)
     head = run_mode(primary, args.steps, extra_headline, min_seconds=args.sustain_seconds)
+    # -- the same region with pose weights that hold NO structured zeros (weights.make_openpose_state: every row random) and frames of
+    #    noise: the chip clocks to its power budget and the power an MFMA draws depends on its operands, so the decoder weights
+    #    (20 - 45 % zeros in conv3_x / conv4_x / stage 6: terran_amd/weights.py) may flatter the figure.  Both legs are in the line
+    #    with their power objects; if they differ by more than 2 % the un-zeroed one IS the headline (`value`).
+    legs = {'decoder_pose_weights': head}
+    headline_leg = 'decoder_pose_weights'
+    if (args.side and not (args.serial or args.join_steps)) or os.environ.get('TA_BENCH_RANDOM_LEG'):
+        from terran_amd import synth, weights
+        work.update(sd_p=weights.make_openpose_state(), frames=synth.frames(900 + rank, args.batch, H, W))
+        try:
+            legs['random_pose_weights'] = run_mode(primary, args.steps, min_seconds=args.sustain_seconds)
+        finally:
+            work.update(sd_p=sd_p, frames=frames_host)
+        a_, b_ = (args.batch * r['steps'] / r['elapsed'] for r in (legs['decoder_pose_weights'], legs['random_pose_weights']))
+        if abs(a_ - b_) > 0.02 * max(a_, b_):
+            headline_leg = 'random_pose_weights'
+            for k_ in ('ingest',):                                # measured with the decoder workload's models loaded: stays with the line
+                if k_ in head:
+                    legs['random_pose_weights'][k_] = head[k_]
+            head = legs['random_pose_weights']
     elapsed, steps_timed, out, klass = head['elapsed'], head['steps'], head['out'], head['klass']
+
+    def drift(res):
+        """Discrete results of a leg's last step against the exact-f32 leg's on the same frames: detections (rounded boxes, as sets per
+        frame), people (keypoint arrays as sets per frame), and the embeddings of the faces both legs embedded."""
+        base = others.get('f32', {}).get('_out') if res is not others.get('f32') else None
+        if base is None or res.get('_out') is None:
+            return None
+        (d0, f0, p0), (d1, f1, p1) = base, res['_out']
+        key = lambda d: tuple(np.rint(d['bbox']).astype(int).tolist())
+        nd = sum(len(x) for x in d0)
+        dd = sum(len({key(x) for x in a} ^ {key(x) for x in b}) for a, b in zip(d0, d1))
+        nh = sum(len(x) for x in p0)
+        dh = sum(len({x['keypoints'].tobytes() for x in a} ^ {x['keypoints'].tobytes() for x in b}) for a, b in zip(p0, p1))
+        emb = 0.0
+        for a, b, fa, fb in zip(d0, d1, f0, f1):
+            for i in range(min(len(fa), len(fb), len(a), len(b))):
+                if key(a[i]) == key(b[i]):
+                    emb = max(emb, float(np.abs(np.asarray(fa[i]) - np.asarray(fb[i])).max()))
+        return {'vs': 'the exact-f32 leg, last step of the region (same frames)', 'detections': nd, 'detections_differ': dd,
+                'people': nh, 'people_differ': dh, 'embedding_max_abs_diff': round(emb, 7)}
     others = {}
-    if not args.single_mode:
-        for prec in ('f32', 'f16x3', 'bf16x3', 'f16'):
+    primary_drift = None
+    if args.side:
+        for prec in ('f32', 'f16x3', 'bf16x3', 'f16', 'f16x2', 'bf16'):
             if prec != primary:
                 r2 = run_mode(prec, max(L, args.steps // 2), min_seconds=args.side_seconds)
                 others[prec] = {'value': fps(r2['elapsed'], r2['steps']), 'steps': r2['steps'],
                                 'timed_region_s': round(r2['elapsed'], 3),
                                 'ms_per_step': round(r2['elapsed'] / r2['steps'] * 1e3, 3),
-                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm']), 'power': r2.get('power')}
+                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm']), 'power': r2.get('power'), '_out': r2['out']}
+        legs['decoder_pose_weights']['_out'] = legs['decoder_pose_weights']['out']
+        for prec, o in list(others.items()) + [(primary, legs['decoder_pose_weights'])]:
+            dr = drift(o)
+            if dr is not None:
+                o['decision_drift'] = dr
+        primary_drift = legs['decoder_pose_weights'].get('decision_drift')
+        for o in others.values():
+            o.pop('_out', None)
 
     # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
     other_faces = {}
-    if not args.single_mode:
+    if args.side:
         for nf in (1, 4):
             if nf != F:
                 face_state['F'] = nf
@@ -617,7 +690,7 @@ def run(args):
     # region of >= 1 s (barrier + sync on both sides, max over ranks).  north_star asks for the 640 x 640 figures beside the
     # 1080p ones at every N; at N = 1 `per_model` carries the same row with its roofline.
     c2_multi = None
-    if use_dist and not args.single_mode:
+    if use_dist and args.side:
         from terran_amd import retinaface, synth
         det640 = retinaface.RetinaFace(device=device_index, state=sd_r, precision=primary, ctx=pipes[0].ctxs[0])
         fr640 = pipes[0].ctxs[0].upload(synth.frames(1 + rank, 32, 640, 640))
@@ -643,10 +716,14 @@ def run(args):
         fr640.free()
         det640.model.free()
     placements = [affinity.describe(placement)]
+    host_per_rank = [dict(legs['decoder_pose_weights'].get('host') or {}, cores_allowed=len(os.sched_getaffinity(0)))]
     if use_dist:
         gathered_pl = [None] * world
         dist.all_gather_object(gathered_pl, affinity.describe(placement), group=gather_group)
         placements = gathered_pl
+        gathered_h = [None] * world
+        dist.all_gather_object(gathered_h, host_per_rank[0], group=gather_group)
+        host_per_rank = gathered_h
 
     result = None
     if rank == 0:
@@ -676,9 +753,13 @@ def run(args):
             'config': {
                 'workload': 'BASELINE configs[4]: 1080p frames, %d per GPU per step, resident in HBM; '
                             'Detection(short_side=416) + Recognition(top-%d faces/frame) + '
-                            'Estimation(short_side=184); random-init weights (seeds 100/101/102; the pose weights '
-                            'carry the decoder path that turns the frames\' embedded pose maps into 4 people per frame)'
-                            % (args.batch, F),
+                            'Estimation(short_side=184); random-init weights (seeds 100/101/102); %s'
+                            % (args.batch, F,
+                               'the pose weights carry the decoder path that turns the frames\' embedded pose maps into 4 people per frame'
+                               if headline_leg == 'decoder_pose_weights' else
+                               'pose weights WITHOUT structured zeros (weights.make_openpose_state) on frames of noise: this leg differs by more '
+                               'than 2 % from the decoder-weights leg (`value_decoder_pose_weights`), so it is the headline'),
+                'headline_leg': headline_leg,
                 'precision': primary,
                 'frames_per_gpu_step': args.batch,
                 'faces_per_frame': F,
@@ -688,6 +769,9 @@ def run(args):
                 'pose_limb_connections_per_frame': round(pipes[0].ctxs[2].pose_stats()[1] / float(args.batch), 1),
                 'sharding': 'frames split over ranks, no data-path collective',
                 'host_placement_per_rank': placements,
+                # per rank: CPU-seconds the whole process (every lane's threads) burned per step of the timed region, its live threads and
+                # the cores it may run on -- the host side has to stay under the GPU's step time on its share of the node's cores
+                'host_per_rank': host_per_rank,
                 'streams_per_gpu': 4 * L if args.lane_embedders else 3 * L + 1,
                 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                 'batches_in_flight_per_gpu': L,
@@ -722,6 +806,12 @@ def run(args):
                     a_, b_ = work.get(name, (0, 0.0))
                     work[name] = (a_ + n_, b_ + fl)
             result['kernel_work_run'] = {k_: {'launches': v[0], 'gflop': round(v[1] / 1e9, 2)} for k_, v in sorted(work.items())}
+        for name, leg in legs.items():                               # both workloads of the headline mode, each with its power object
+            result['value_' + name] = fps(leg['elapsed'], leg['steps'])
+            result['power_' + name] = leg.get('power')
+            result['ms_per_step_' + name] = round(leg['elapsed'] / leg['steps'] * 1e3, 3)
+        if primary_drift is not None:
+            result['decision_drift'] = primary_drift
         if 'f32' in others:                                          # the like-for-like reference arithmetic, top level
             result['value_f32'] = others['f32']['value']
             result['ms_per_step_f32'] = others['f32']['ms_per_step']
@@ -731,6 +821,9 @@ def run(args):
             result['value_f16x3'] = others['f16x3']['value']
             result['ms_per_step_f16x3'] = others['f16x3']['ms_per_step']
             result['roofline_f16x3'] = others['f16x3']['roofline']
+        if 'bf16' in others:                                         # BASELINE configs[1]'s "bf16": the throughput mode, with its measured drift
+            result['value_bf16'] = others['bf16']['value']
+            result['decision_drift_bf16'] = others['bf16'].get('decision_drift')
         if 'f16' in others:                                          # opt-in tolerance mode for the embedder alone (see DTYPES['f16'])
             result['value_f16_embedder'] = others['f16']['value']
             result['ms_per_step_f16_embedder'] = others['f16']['ms_per_step']
@@ -758,7 +851,7 @@ def run(args):
     for p in pipes:
         p.free()
     pool.shutdown()
-    if rank == 0 and world == 1 and not args.single_mode:
+    if rank == 0 and world == 1 and args.side:
         try:
             result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'])
         except Exception as ex:
@@ -880,23 +973,22 @@ def per_model(ctx, precisions, reps=8):
         dt, prof = timed(lambda: arc.embed_crops(c3), max(2, reps // 2))
         tf = prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9
         peak, _, factor = PEAKS[prec]
-        if prec == 'f16':
-            factor = 1                               # the embedder itself: one MFMA per product
+        emb_factor = {'f16': 1, 'f16x2': 2}.get(prec, factor)      # the embedder itself: MFMAs per product
         rows['C3 ArcFace 256x3x112x112 ' + prec] = {
             'images_per_s': round(256 / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'conv_ms': round(prof['conv_igemm'][0], 3),
             'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'achieved': round(tf, 1), 'frac': round(tf / peak, 4),
-                         'mfma_issue_frac': round(tf * factor / peak, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP}}
+                         'mfma_issue_frac': round(tf * emb_factor / peak, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP}}
         arc.model.free()
-        if prec in ('f16x3', 'f16'):                 # the embedder in its other mode beside it (single-half <-> float32-grade)
-            alt = 'f16' if prec == 'f16x3' else 'f16x3'
+        for alt in ([m for m in ('f16x2', 'f16x3', 'f16') if m != prec] if prec in ('f16x2', 'f16x3', 'f16') else []):     # the embedder's other modes beside it
             arc = arcface.ArcFace(device=ctx.device_id, state=sd_a, precision=alt, ctx=ctx)
             dt, prof = timed(lambda: arc.embed_crops(c3), max(2, reps // 2))
             tf = prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9
             rows['C3 ArcFace 256x3x112x112 (embedder in the %s mode)' % alt] = {
                 'images_per_s': round(256 / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'conv_ms': round(prof['conv_igemm'][0], 3),
                 'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0, 'achieved': round(tf, 1), 'frac': round(tf / 2500.0, 4),
-                             'mfma_issue_frac': round(tf * (1 if alt == 'f16' else 3) / 2500.0, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP,
-                             'note': 'f16: one f16 MFMA per product on 2-byte half-float activations, embeddings 3.6e-4 vs the 1e-3 bar; '
+                             'mfma_issue_frac': round(tf * {'f16': 1, 'f16x2': 2}.get(alt, 3) / 2500.0, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP,
+                             'note': 'f16: one f16 MFMA per product on 2-byte half-float activations, embeddings 3.3e-4 (wild-statistics weights 1.8e-3) vs the 1e-3 bar; '
+                                     'f16x2 (default): two per product, (w_hi + w_lo) * x_hi, embeddings 1.8e-4 (8.2e-4); '
                                      'f16x3: three per product on split-half operands, embeddings 5e-7'}}
             arc.model.free()
         pose = openpose.OpenPose(device=ctx.device_id, short_side=368, state=sd_p, precision=prec, ctx=ctx)

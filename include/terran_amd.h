@@ -37,9 +37,10 @@ extern "C" {
 #define TA_E_DEVICE (-2)    /* HIP error, no device, or out of device memory  */
 #define TA_E_CAPACITY (-3)  /* caller-provided result arrays are too small    */
 #define TA_E_OVERFLOW (-4)  /* an addressing limit was hit (ta_openpose_run: more than 65535 peaks of ONE body part in one image) */
-#define TA_E_RANGE (-5)     /* f16x3 / f16 arithmetic modes only: an activation left the half-float range (stored |x| > 65504, inf
+#define TA_E_RANGE (-5)     /* f16x3 / f16x2 / f16 arithmetic modes only: an activation left the half-float range (stored |x| > 65504, inf
                              * or NaN; tensors are stored times a pack-time power of two that puts the expected maximum near 2^10);
-                             * no numbers are returned -- run the input on a model packed for f32 (or bf16x3)            */
+                             * no numbers are returned -- run the input on a model packed for f32 (or bf16x3).  Checked on every tensor
+                             * some op READS; final float32 results no op reads (embeddings, detector heads) are not range-checked */
 
 #define TA_MODEL_RETINAFACE 1
 #define TA_MODEL_ARCFACE 2
@@ -214,6 +215,10 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
 #define TA_CONV_SPLIT_2x2_P8 5 /* ... with 8 producer waves                                          */
 #define TA_CONV_SPLIT_2x4 6    /* producer/consumer waves, 128 cout x 256 px (8 consumer waves)      */
 #define TA_CONV_SPLIT_1x4 7    /* producer/consumer waves, 64 cout x 256 px                          */
+#define TA_CONV_WIN_2x2 8      /* ... 128 x 128 with the pixel operand of a channel block resident in LDS (stride-1 convs with >= 4 taps on
+                                * pre-split half-float tensors; the K-split and the fused pool stay with the streaming kernels)  */
+#define TA_CONV_WIN_2x4 9      /* ... 128 x 256                                                       */
+#define TA_CONV_WIN_1x4 10     /* ... 64 cout x 256 px                                                */
 int ta_debug_conv_variant(ta_ctx* ctx, int variant);
 /* f16x3 mode: after ta_model_forward_* (the debug taps; the task entry points do this themselves), wait for the stream
  * and report whether an epilogue met |x| > 65504: TA_OK or TA_E_RANGE.  Clears the condition. */

@@ -65,9 +65,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Weights are split at pack time ([hi x32 | lo x32] 16-bit words per 128-byte row).  Activations either arrive in the
 // same image (TA_FMT_SPLIT / TA_FMT_SPLIT16, written by the producer's epilogue) or are float32 and split in registers
 // right after the ds_read.
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16X3 = 3, PREC_F16 = 4 };
+//   PREC_F16X2  : TWO of the three products on the same operands as PREC_F16X3: (w_hi + w_lo) * x_hi -- the weights keep their 22 bits,
+//                 every activation enters the contraction rounded to its hi half (11 bits; the `lo` words of the pre-split tensors
+//                 are simply not read, so the shortcut trunk of a residual network still carries 22 bits from unit to unit).  A
+//                 tolerance mode for networks that take no discrete decision (the embedder: tests/probe_embed_2mfma.py), 2/3 of the
+//                 MFMAs of PREC_F16X3; tensors, weight image, scales and range flag are PREC_F16X3's.
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_F16X3 = 3, PREC_F16 = 4, PREC_F16X2 = 5 };
 __host__ __device__ constexpr bool prec_x3(int prec) { return prec == PREC_BF16X3 || prec == PREC_F16X3; }
-__host__ __device__ constexpr bool prec_half(int prec) { return prec == PREC_F16X3 || prec == PREC_F16; }   // IEEE half words (else bf16)
+__host__ __device__ constexpr bool prec_x2(int prec) { return prec == PREC_F16X2; }                        // w_lo * x_hi + w_hi * x_hi
+__host__ __device__ constexpr bool prec_half(int prec) { return prec == PREC_F16X3 || prec == PREC_F16 || prec == PREC_F16X2; }   // IEEE half words (else bf16)
+__host__ __device__ constexpr int prec_nmma(int prec) { return prec_x3(prec) ? 3 : (prec_x2(prec) ? 2 : 1); }   // MFMAs per product term (16-bit modes)
 
 // one 32x32x16 MFMA on 16-bit operand fragments held as raw bits (bf16x8 is the container type for both formats)
 template <int PREC>
@@ -137,11 +144,9 @@ __device__ __forceinline__ unsigned ta_amax4(unsigned m, const f32x4& v) {
 // end of an epilogue: raise the flag; tools (ta_model_debug_amax) also collect the maximum itself per op
 __device__ __forceinline__ void ta_range_report(const ta_conv_launch& p, unsigned amax) {
   if (amax > TA_F16_MAX_BITS) *p.range_flag = 1;
-  if (p.amax_index >= 0) {                        // tools: the slots live behind the flag word (ta_ctx::range_flag, TA_AMAX_SLOT0)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
-    if ((threadIdx.x & 63) == 0 && amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index, amax);
-  }
+  // tools: the slots live behind the flag word (ta_ctx::range_flag, TA_AMAX_SLOT0).  Every lane reports its own maximum: callers
+  // reach this point with part of the wave already returned, so a cross-lane reduction here would read exited lanes
+  if (p.amax_index >= 0 && amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index, amax);
 }
 // ReLU that keeps a NaN a NaN (`v > 0 ? v : 0` turns it into 0 and hides it from the range guard)
 __device__ __forceinline__ float ta_relu(float v) { return v < 0.f ? 0.f : v; }
@@ -363,7 +368,7 @@ __device__ __forceinline__ void conv_slab_mma(const float* st, f32x16 (&acc)[WM_
 #pragma unroll
       for (int a = 0; a < WM_TILES; ++a) {
         ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-        if constexpr (prec_x3(PREC)) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+        if constexpr (prec_x3(PREC) || prec_x2(PREC)) al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
       }
 #pragma unroll
       for (int b = 0; b < WN_TILES; ++b) {
@@ -380,12 +385,14 @@ __device__ __forceinline__ void conv_slab_mma(const float* st, f32x16 (&acc)[WM_
           }
         }
       }
-      if constexpr (prec_x3(PREC)) {
+      if constexpr (prec_x3(PREC) || prec_x2(PREC)) {
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
           for (int b = 0; b < WN_TILES; ++b)
             acc[a][b] = ta_mfma16<PREC>(al[a], bh[b], acc[a][b]);
+      }
+      if constexpr (prec_x3(PREC)) {
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 #pragma unroll
         for (int a = 0; a < WM_TILES; ++a) {
           f.ah[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-          if constexpr (prec_x3(PREC)) f.al[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+          if constexpr (prec_x3(PREC) || prec_x2(PREC)) f.al[a][t] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
         }
 #pragma unroll
         for (int b = 0; b < WN_TILES; ++b) {
@@ -723,12 +730,14 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        if constexpr (prec_x3(PREC)) {
+        if constexpr (prec_x3(PREC) || prec_x2(PREC)) {
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
             for (int b = 0; b < WN_TILES; ++b)
               acc[a][b] = ta_mfma16<PREC>(f.al[a][t], f.bh[b][t], acc[a][b]);
+        }
+        if constexpr (prec_x3(PREC)) {
 #pragma unroll
           for (int a = 0; a < WM_TILES; ++a)
 #pragma unroll
@@ -786,8 +795,8 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
     if constexpr (PREC != PREC_F32 && !BSPLIT) {
       // hipcc otherwise emits the MFMAs back to back and the hi/lo split after them: pin an interleave
       // (all fragment reads first, then 1 MFMA : VPM VALU) so the split runs in the MFMA shadows.
-      constexpr int NREAD = 2 * (WM_TILES * (prec_x3(PREC) ? 2 : 1) + 2 * WN_TILES);
-      constexpr int NMFMA = 2 * WM_TILES * WN_TILES * (prec_x3(PREC) ? 3 : 1);
+      constexpr int NREAD = 2 * (WM_TILES * ((prec_x3(PREC) || prec_x2(PREC)) ? 2 : 1) + 2 * WN_TILES);
+      constexpr int NMFMA = 2 * WM_TILES * WN_TILES * prec_nmma(PREC);
       constexpr int VPM = (prec_x3(PREC) ? 58 : 30) * WN_TILES / NMFMA + 1;
       __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
@@ -955,11 +964,7 @@ __global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   if (wave == 0) TA_STAMP(20);                      // MFMAs issued
   if constexpr (PREC != PREC_F32) {
     if (dw_amax > TA_F16_MAX_BITS) *p.range_flag = 1;
-    if (p.amax_index >= 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) dw_amax = max(dw_amax, (unsigned)__shfl_xor((int)dw_amax, o));
-      if (lane == 0 && dw_amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index + 1, dw_amax);
-    }
+    if (p.amax_index >= 0 && dw_amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index + 1, dw_amax);
   }
   conv_finish_sym<WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, acc, lds, ct0, pt0, wm, wn, tid, lane, HoWo);
   if (wave == 0) TA_STAMP(23);                      // drained: stores issued
@@ -1614,7 +1619,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
-      if constexpr (prec_x3(PREC) || PREC == PREC_F16) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      if constexpr (prec_x3(PREC) || prec_x2(PREC) || PREC == PREC_F16) f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -1635,11 +1640,13 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a32[a][g][e], f.b32[b][g][e], acc[a][b], 0, 0, 0);
       return;
     }
-    if constexpr (prec_x3(PREC)) {
+    if constexpr (prec_x3(PREC) || prec_x2(PREC)) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.al[a], f.bh[b], acc[a][b]);
+    }
+    if constexpr (prec_x3(PREC)) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1656,8 +1663,8 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bh[b], acc[a][b]);
   };
-  constexpr int NREAD = PREC == PREC_BF16 ? 4 : 8;                               // ds_read_b128 per k-step
-  constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : (PREC == PREC_F16 ? 8 : 4));         // MFMAs per k-step
+  constexpr int NREAD = PREC == PREC_BF16 ? 4 : (prec_x2(PREC) ? 6 : 8);          // ds_read_b128 per k-step
+  constexpr int NMMA = PREC == PREC_F32 ? 32 : (prec_x3(PREC) ? 12 : ((PREC == PREC_F16 || prec_x2(PREC)) ? 8 : 4));         // MFMAs per k-step
   // pin "reads first, one per MFMA slot, then the remaining MFMAs": hipcc otherwise sinks the reads next to their
   // use to save registers and exposes the LDS latency in front of every group of MFMAs
   auto pin = [&]() {
@@ -1710,6 +1717,253 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     if (!done) conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, ks);
   }
   if (wave == 0) TA_STAMP(4);                       // consumer: epilogue stores issued
+}
+
+// ---- split-role kernel with a WINDOW-RESIDENT pixel operand (3x3 / 7x7 stride-1 convs on pre-split half-float tensors) --------
+// conv_igemm_split streams both operands per K slab: over the kh x kw taps of one channel block the same input pixels are
+// fetched kh x kw times from L2 into LDS (each time shifted by one tap).  Here the pixel operand of a channel block is loaded
+// ONCE: the tile's BM pixels are consecutive interior pixels in raster order, so every tap of every one of them lies inside
+// one contiguous run of the padded tensor -- from the first pixel's tap (0, 0) to the last pixel's tap (kh-1, kw-1), halo
+// rows and, where a tile crosses into the next image, the halo rows between the images included.  That run (<= PR pixel rows
+// of 128 bytes: one 32-channel block, [hi x32 | lo x32]) is the PATCH.  Producers DMA patch cb + 1 into the second patch
+// buffer while the kh x kw slabs of block cb are consumed; per slab only the weight rows stream (BN x 128 bytes instead of
+// (BN + BM) x 128).  A consumer lane keeps the patch row of its two pixels and reads tap (ky, kx) at row + ky * Wp + kx -- the
+// same XOR swizzle on the row index, so the fragment reads stay conflict-free (16 consecutive rows per quarter wave).
+// K order, MFMA order and epilogue are conv_igemm_split's: a layer's bits do not depend on which of the two kernels runs it.
+// L2 -> LDS bytes per tile and channel block: kh kw BN 128 + ~1.5 BM 128 instead of kh kw (BN + BM) 128 (3x3, 128 x 128:
+// 172 KiB instead of 288; the embedder's two-product mode is bound by exactly this stream).
+template <int CM, int CN, int PREC, int PR>
+__global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_igemm_win(const ta_conv_launch p) {
+  static_assert(prec_half(PREC) && PREC != PREC_F16, "pre-split half-float tensors (f16x3 / f16x2)");
+  static_assert(CM * CN == 4 || CM * CN == 8, "consumer grid: 1x4 (64 cout x 256 px), 2x2 (128 x 128) or 2x4 (128 x 256)");
+  static_assert(PR % 32 == 0, "whole DMA instructions per producer wave");
+  constexpr int NC = CM * CN, NP = 4;
+  constexpr int BN = CM * 64, BM = CN * 64;
+  constexpr int QA = BN / 8 / NP;                // weight-row DMA instructions per producer wave per slab
+  constexpr int NPW = PR / 8 / NP;               // patch DMA instructions per producer wave per channel block
+  constexpr int A_STAGE = BN * 32;               // floats per weight stage (3 stages)
+  constexpr int PATCH = PR * 32;                 // floats per patch buffer (2 buffers)
+  static_assert(QA + NPW < 64, "s_waitcnt vmcnt is a 6-bit count");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const patch0 = lds + 3 * A_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int bid = blockIdx.x;
+  const int grp = bid >> 3, xcd = bid & 7;
+  const int gq = ta_div_r(grp, n_ct, p.r_nct, p.fast_div);
+  const int pt = ta_xcd_tile(n_pt, xcd, gq);
+  if (pt < 0) return;
+  const int ct0 = (grp - gq * n_ct) * BN;
+  const int pt0 = pt * BM;
+  const int HoWo = p.Ho * p.Wo;
+  const int S = p.n_slabs;
+  const int T = p.k_w * p.k_h;                   // slabs per channel block
+  // padded-raster index of a pixel's tap (0, 0) relative to the tile's first pixel: the patch row it reads at that tap
+  const ta_pixel_walk walk(p, pt0, HoWo);
+  const int wp = p.win_wp, wimg = p.win_img;    // pixels per padded row / per padded image (launcher)
+
+  if (wave >= NC) {
+    // ================= producer =================
+    const int pw = wave - NC;
+    const int pchunk = lane & 7;
+    const int lchunk = pchunk ^ ((4 * (pw & 1) + (lane >> 4)) & 7);
+    const char* a_base = (const char*)p.w;
+    const size_t a_slab_bytes = (size_t)p.coutp * 128;
+    unsigned a_off[QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) a_off[q] = (unsigned)(((ct0 + (q * NP + pw) * 8 + (lane >> 3)) * 32 + lchunk * 4) * 4);
+    ta_k_walk wa(p, 0);
+    auto issue_a = [&](int stage) {
+#pragma unroll
+      for (int q = 0; q < QA; ++q) ta_dma16(a_base + (size_t)wa.a_slab * a_slab_bytes, a_off[q], lds + stage * A_STAGE + (q * NP + pw) * 256);
+      wa.advance();
+    };
+    issue_a(0);                                     // needs no pixel arithmetic: moving first
+    // the patch: rows 0 .. n_patch - 1 of the padded tensor from the first pixel's tap (0, 0) on
+    const int last = (p.M - pt0 < BM ? p.M - pt0 : BM) - 1;
+    int img1, y1, x1;
+    walk.at(last, img1, y1, x1);
+    const int n_patch = (img1 - walk.img0) * wimg + (y1 - walk.y0) * wp + (x1 - walk.x0) + (p.k_h - 1) * wp + p.k_w;
+    const int in_ch = p.in_ch_off + (p.group_cout ? (ct0 / p.group_cout) * p.group_cin : 0);
+    const size_t off0 = (size_t)walk.img0 * p.in_img + (size_t)walk.y0 * p.in_row + (size_t)walk.x0 * p.in_pix + p.in_off0 + in_ch;
+    const char* b_base = (const char*)(p.in + off0);
+    unsigned p_off[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int r = (i * NP + pw) * 8 + (lane >> 3);                      // LDS row; rows past the patch re-read its last row
+      const int rr = r < n_patch ? r : n_patch - 1;
+      p_off[i] = (unsigned)rr * (unsigned)(p.in_pix * 4) + (unsigned)(lchunk * 16);
+    }
+    auto issue_patch = [&](int cb) {
+      float* dst = patch0 + (cb & 1) * PATCH;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) ta_dma16(b_base + (size_t)cb * 128, p_off[i], dst + (i * NP + pw) * 256);
+    };
+    issue_patch(0);
+    if (S > 1) issue_a(1);
+    int stage = 2, t = 0, cb = 0;
+    bool patch_behind = false;                      // a patch was issued right after the previous barrier
+    for (int g = 0; g < S; ++g) {
+      // vmcnt counts in issue order: [A0 P0 A1], then per barrier [P(cb+1) if tap 0] A(g+2).  Slab g's weight rows must have
+      // landed; what may stay in flight is the next slab's rows and a patch issued behind slab g's rows
+      const bool more = g + 1 < S;
+      if (patch_behind) {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA + NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      } else {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                 // B_g: slab g (and, at tap 0, its patch) landed; consumers drained slab g-1
+      asm volatile("" ::: "memory");
+      patch_behind = false;
+      if (t == 0 && cb + 1 < p.k_cblocks) {         // the other patch buffer was last read by block cb-1: free since this barrier
+        issue_patch(cb + 1);
+        patch_behind = true;
+      }
+      if (g + 2 < S) {
+        issue_a(stage);
+        stage = stage == 2 ? 0 : stage + 1;
+      }
+      if (++t == T) {
+        t = 0;
+        ++cb;
+      }
+    }
+    // (a patch is never left in flight here: the last block issues none)
+    {
+      __builtin_amdgcn_s_barrier();                 // E0
+      __builtin_amdgcn_s_barrier();                 // E1
+      asm volatile("" ::: "memory");
+      if (!conv_drain_dispatch<BN, BM, 64 * (NC + NP), 1>(p, lds, ct0, pt0, tid, HoWo))
+        conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, 0);
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  const int cm = wave / CN, cn = wave % CN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int kg = lane >> 5;
+  const int a_row0 = cm * 64 + frow;
+  int rB[2];                                        // patch row of this lane's two pixels at tap (0, 0)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int d = cn * 64 + b * 32 + frow;
+    int img, y, x;
+    walk.at(pt0 + d < p.M ? d : 0, img, y, x);     // pixels past M: the tile's first pixel (their stores are masked)
+    rB[b] = (img - walk.img0) * wimg + (y - walk.y0) * wp + (x - walk.x0);
+  }
+  struct Frag {
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+  };
+  unsigned pb[2];                                   // byte offset (inside the patch buffers) of this slab's B rows, k-step 0, hi words
+  auto baddr = [&](int tap_off, int buf) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned row = (unsigned)(rB[b] + tap_off);
+      pb[b] = (unsigned)buf * (unsigned)(PATCH * 4) + row * 128u + ((((unsigned)(2 * kg)) ^ ((row >> 1) & 7u)) << 4);
+    }
+  };
+  auto load = [&](Frag& f, const float* st, int t) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f.ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+      f.al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const char* q = (const char*)patch0 + (pb[b] ^ (unsigned)(t << 4));      // chunk 2 kg + t: bit 0 of the chunk index
+      f.bh[b] = *(const bf16x8*)q;
+      if constexpr (prec_x3(PREC)) f.bl[b] = *(const bf16x8*)((const char*)patch0 + ((pb[b] ^ (unsigned)(t << 4)) ^ 64u));   // + 4 chunks: the lo words
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.al[a], f.bh[b], acc[a][b]);
+    if constexpr (prec_x3(PREC)) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bl[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = ta_mfma16<PREC>(f.ah[a], f.bh[b], acc[a][b]);
+  };
+  constexpr int NREAD = prec_x3(PREC) ? 8 : 6;
+  constexpr int NMMA = prec_x3(PREC) ? 12 : 8;
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < NREAD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMMA - NREAD, 0);
+  };
+  // K walk of the consumer side (scalar): tap offset inside the patch and the patch buffer of the slab being read
+  int kx = 0, ky = 0, cb = 0, tap_off = 0, stage = 0;
+  Frag F0, F1;
+  baddr(0, 0);
+  __builtin_amdgcn_s_barrier();                     // B_0
+  asm volatile("" ::: "memory");
+  load(F0, lds, 0);
+  for (int g = 0; g + 1 < S; ++g) {
+    const float* st = lds + stage * A_STAGE;
+    stage = stage == 2 ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    load(F1, st, 1);
+    mma(F0);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+    // the next slab's tap (scalar walk) and its B addresses, while the reads of this slab return
+    if (++kx == p.k_w) {
+      kx = 0;
+      tap_off += wp - p.k_w;
+      if (++ky == p.k_h) {
+        ky = 0;
+        ++cb;
+        tap_off = -1;
+      }
+    }
+    ++tap_off;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment of slab g is in registers
+    baddr(tap_off, cb & 1);
+    __builtin_amdgcn_s_barrier();                          // B_{g+1}
+    asm volatile("" ::: "memory");
+    load(F0, lds + stage * A_STAGE, 0);
+    mma(F1);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load(F1, lds + stage * A_STAGE, 1);
+  mma(F0);
+  mma(F1);
+  {
+    __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: ring and patches can be reused
+    asm volatile("" ::: "memory");
+    conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // E1: tile parked
+    asm volatile("" ::: "memory");
+    if (!conv_drain_dispatch<BN, BM, 64 * (NC + NP), 1>(p, lds, ct0, pt0, tid, HoWo))
+      conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, 0);
+  }
 }
 
 // Second pass of a K-split conv: out = act(sum_k partial[k] + bias), ranges added in ascending order (deterministic).
@@ -1807,6 +2061,60 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, p);
     TA_HIP(ctx, hipGetLastError());
   }
+  return TA_OK;
+}
+
+// patch rows a BM-pixel tile of this launch can need at most (conv_igemm_win): BM - 1 raster steps, each output row crossed adds
+// the two halo columns, each image crossed the halo rows between the images, plus the taps of the last pixel
+static int win_patch_rows(const ta_conv_launch& p, int BM) {
+  if (p.Wo <= 0 || p.Ho <= 0 || p.win_wp <= 0) return 1 << 30;
+  const long long n = BM - 1, hp = p.win_img / p.win_wp;
+  const long long rows = n + ((n + p.Wo - 1) / p.Wo) * (p.win_wp - p.Wo) + ((n + (long long)p.Ho * p.Wo - 1) / ((long long)p.Ho * p.Wo)) * (hp - p.Ho) * p.win_wp +
+                         (long long)(p.k_h - 1) * p.win_wp + p.k_w;
+  return rows > (1 << 30) ? (1 << 30) : (int)rows;
+}
+// what the window kernels are instantiated with: patch capacity per tile shape (LDS: 3 weight stages + 2 patches <= 160 KiB)
+#define TA_WIN_PR_2x2 384
+#define TA_WIN_PR_2x4 448
+#define TA_WIN_PR_1x4 512
+
+template <int CM, int CN, int PREC, int PR>
+static int launch_win(ta_ctx* ctx, const ta_conv_launch& p) {
+  constexpr int BN = CM * 64, BM = CN * 64;
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int groups = ((n_pt + 7) / 8) * n_ct;
+  constexpr size_t ring = (size_t)(3 * BN + 2 * PR) * 128, park = (size_t)BM * BN * 4;
+  constexpr size_t lds_bytes = ring > park ? ring : park;
+  static_assert(lds_bytes <= 160 * 1024, "one workgroup's LDS");
+  auto kern = conv_igemm_win<CM, CN, PREC, PR>;
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
+  ta_conv_launch q = p;
+  const long long grid = (long long)groups * 8;
+  q.r_nct = 1.0f / (float)n_ct;
+  q.r_tile_blocks = 1.0f / (float)(groups * 8);
+  q.r_Wo = 1.0f / (float)p.Wo;
+  q.r_Ho = 1.0f / (float)p.Ho;
+  q.r_HoWo = 1.0f / (float)(p.Ho * p.Wo);
+  {
+    static const bool no_fast_drain = getenv("TA_CONV_NO_FASTDRAIN") != nullptr;
+    const long long n_img = ((long long)p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo);
+    auto fits = [&](long long img_stride, int off0) { return ((n_img + 1) * img_stride + off0) * 4 < (1LL << 32); };
+    bool ok = !no_fast_drain && p.out_fmt == TA_FMT_SPLIT16 && (p.cout & 7) == 0 && ((p.out_ch | p.res_ch | p.o2_ch) & 7) == 0 && fits(p.out_img, p.out_off0);
+    if (p.res) ok = ok && p.res_fmt == TA_FMT_SPLIT16 && fits(p.res_img, p.res_off0);
+    if (p.out2) ok = ok && p.o2_fmt == TA_FMT_SPLIT16 && fits(p.o2_img, p.o2_off0);
+    q.fast_drain = ok ? 1 : 0;
+    if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;
+  }
+  q.fast_div = (grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;
+  q.k_split = 1;
+  {
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "conv_igemm_win<%d,%d,%d,%d>", CM, CN, PREC, PR);
+    ctx->note_kernel(name);
+  }
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(64 * (CM * CN + 4)), lds_bytes, ctx->stream, q);
+  TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }
 
@@ -1919,12 +2227,34 @@ static bool variant_eligible(int v, const ta_conv_launch& p) {
     case TA_CV_SPLIT_2x2_P8:
     case TA_CV_SPLIT_2x4: return deep && split_in && staged && p.coutp % 128 == 0;
     case TA_CV_SPLIT_1x4: return deep && split_in && staged && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0);
+    case TA_CV_WIN_2x2:
+    case TA_CV_WIN_2x4:
+    case TA_CV_WIN_1x4: {
+      // window-resident pixel operand: stride-1 convs with >= 4 taps on pre-split half-float tensors (f16x3 / f16x2), no fused
+      // pool, no K ranges, and a patch that fits the instantiated capacity
+      const bool base = deep && split_in && staged && (p.prec == PREC_F16X3 || p.prec == PREC_F16X2) && p.stride == 1 && !p.pool && p.k_split <= 1 &&
+                        p.k_w * p.k_h >= 4 && p.n_slabs == p.k_w * p.k_h * p.k_cblocks;
+      if (!base) return false;
+      if (v == TA_CV_WIN_1x4) return p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0) && win_patch_rows(p, 256) <= TA_WIN_PR_1x4;
+      if (p.coutp % 128) return false;
+      return v == TA_CV_WIN_2x2 ? win_patch_rows(p, 128) <= TA_WIN_PR_2x2 : win_patch_rows(p, 256) <= TA_WIN_PR_2x4;
+    }
   }
   return false;
 }
 
 // The automatic choice.
+static int choose_variant_streamed(const ta_conv_launch& p);
 static int choose_variant(const ta_conv_launch& p) {
+  const int v = choose_variant_streamed(p);
+  // the same tile with the pixel operand window-resident, wherever the layer qualifies (stride-1 3x3 / 7x7 on pre-split half-float
+  // tensors whose patch fits): same bits, fewer L2 -> LDS bytes.  TA_CONV_NO_WIN: A/B switch for tools
+  static const bool no_win = getenv("TA_CONV_NO_WIN") != nullptr;
+  if (no_win) return v;
+  const int w = v == TA_CV_SPLIT_2x2 ? TA_CV_WIN_2x2 : (v == TA_CV_SPLIT_2x4 ? TA_CV_WIN_2x4 : (v == TA_CV_SPLIT_1x4 ? TA_CV_WIN_1x4 : 0));
+  return (w && variant_eligible(w, p)) ? w : v;
+}
+static int choose_variant_streamed(const ta_conv_launch& p) {
   if (p.uniform_k && (p.n_slabs >= 2 || p.prec == PREC_F16)) {
     if (variant_eligible(TA_CV_SPLIT_2x2, p)) {
       if (p.prec != PREC_F32 && p.k_split == 1) {
@@ -1960,6 +2290,15 @@ static int launch_variant(ta_ctx* ctx, int v, const ta_conv_launch& p) {
     case TA_CV_SPLIT_2x2_P8: return launch_split<2, 2, 8, PREC, 3>(ctx, p);
     case TA_CV_SPLIT_2x4: return launch_split<2, 4, 4, PREC, 3>(ctx, p);
     case TA_CV_SPLIT_1x4: return launch_split<1, 4, 4, PREC, 3>(ctx, p);
+    case TA_CV_WIN_2x2:
+    case TA_CV_WIN_2x4:
+    case TA_CV_WIN_1x4:
+      if constexpr (PREC == PREC_F16X3 || PREC == PREC_F16X2) {
+        if (v == TA_CV_WIN_2x2) return launch_win<2, 2, PREC, TA_WIN_PR_2x2>(ctx, p);
+        if (v == TA_CV_WIN_2x4) return launch_win<2, 4, PREC, TA_WIN_PR_2x4>(ctx, p);
+        return launch_win<1, 4, PREC, TA_WIN_PR_1x4>(ctx, p);
+      }
+      break;
   }
   return ta_fail(ctx, TA_E_INVALID, "conv: unknown kernel variant %d", v);
 }
@@ -1973,7 +2312,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   p.probe = ctx->conv_probe;
   if (p.k_split < 1 || !p.partial || no_ksplit) p.k_split = 1;
   if (p.coutp % 32 != 0 || p.cout % 4 != 0) return ta_fail(ctx, TA_E_INVALID, "conv: bad cout padding");
-  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16 && p.prec != PREC_F16X3 && p.prec != PREC_F16)
+  if (p.prec != PREC_F32 && p.prec != PREC_BF16X3 && p.prec != PREC_BF16 && p.prec != PREC_F16X3 && p.prec != PREC_F16 && p.prec != PREC_F16X2)
     return ta_fail(ctx, TA_E_INVALID, "conv: unknown precision mode %d", p.prec);
   if (p.in_fmt != TA_FMT_F32 && p.in_fmt != ta_split_fmt_of(p.prec))
     return ta_fail(ctx, TA_E_INVALID, "conv: input tensor format %d does not belong to precision mode %d", p.in_fmt, p.prec);
@@ -1984,13 +2323,15 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
       return ta_fail(ctx, TA_E_INVALID, "conv: forced kernel variant %d cannot run this layer (cin-uniform %d, slabs %d, coutp %d, "
                      "input format %d, groups %d)", v, p.uniform_k, p.n_slabs, p.coutp, p.in_fmt, p.group_cout ? 1 : 0);
   } else {
-    auto is_split_v = [](int x) { return x == TA_CV_SPLIT_2x2 || x == TA_CV_SPLIT_2x2_P8 || x == TA_CV_SPLIT_2x4 || x == TA_CV_SPLIT_1x4; };
+    auto is_split_v = [](int x) { return x == TA_CV_SPLIT_2x2 || x == TA_CV_SPLIT_2x2_P8 || x == TA_CV_SPLIT_2x4 || x == TA_CV_SPLIT_1x4; };   // (the window kernels have no fused pool)
     const bool prefer = ctx->conv_force && variant_eligible(ctx->conv_force, p) && (!p.pool || is_split_v(ctx->conv_force));
     v = prefer ? ctx->conv_force : choose_variant(p);
     if (!variant_eligible(v, p)) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
   }
+  const bool is_win = v == TA_CV_WIN_2x2 || v == TA_CV_WIN_2x4 || v == TA_CV_WIN_1x4;
   const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4;
   if (!is_split) p.k_split = 1;
+  (void)is_win;
   if (p.pool) {                                      // only the split-role kernel's LDS-staged epilogue knows 2x2 windows
     if (!is_split || p.res || p.out2 || (p.out_ch & 7) || (p.M & 3) || (p.act != TA_ACT_RELU && p.act != TA_ACT_NONE))
       return ta_fail(ctx, TA_E_INVALID, "conv: the fused max-pool needs the split-role kernel and a plain epilogue (variant %d)", v);
@@ -2005,6 +2346,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
     case PREC_BF16X3: return launch_variant<PREC_BF16X3>(ctx, v, p);
     case PREC_F16X3: return launch_variant<PREC_F16X3>(ctx, v, p);
     case PREC_F16: return launch_variant<PREC_F16>(ctx, v, p);
+    case PREC_F16X2: return launch_variant<PREC_F16X2>(ctx, v, p);
     default: return launch_variant<PREC_BF16>(ctx, v, p);
   }
 }

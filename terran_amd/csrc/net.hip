@@ -387,6 +387,8 @@ int ta_model_run_ops(ta_model* m) {
         p.in_img = (int)((size_t)ti.hp() * ti.wp() * ti.cf());
         p.in_row = ti.wp() * ti.cf();
         p.in_pix = ti.cf();
+        p.win_wp = ti.wp();
+        p.win_img = ti.hp() * ti.wp();
         p.in_off0 = (int)(((size_t)(ti.halo - op.pad) * ti.wp() + (ti.halo - op.pad)) * ti.cf());
         p.out_img = (int)((size_t)to.hp() * to.wp() * to.cf());
         p.out_row = to.wp() * to.cf();
@@ -549,7 +551,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
     bool bad = bad_t(op.in) || bad_t(op.out) || (op.res >= 0 && bad_t(op.res)) || (op.out2 >= 0 && bad_t(op.out2));
     if (op.type == TA_OP_CONV) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.cin % 4 || op.cout % 4 || op.coutp % 32 || op.n_slabs <= 0 ||
-            op.stride <= 0 || op.wus_off != op.bias_off + 4 * (int64_t)op.coutp || bad_w(op.wus_off, (size_t)op.coutp * 4) || op.prec < 0 || op.prec > 4 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
+            op.stride <= 0 || op.wus_off != op.bias_off + 4 * (int64_t)op.coutp || bad_w(op.wus_off, (size_t)op.coutp * 4) || op.prec < 0 || op.prec > 5 || bad_w(op.w_off, (size_t)op.n_slabs * op.coutp * 128) ||
             bad_w(op.bias_off, (size_t)op.coutp * 4) || bad_w(op.prelu_off, (size_t)op.coutp * 4) ||
             bad_w(op.scale2_off, (size_t)op.coutp * 4) || bad_w(op.shift2_off, (size_t)op.coutp * 4) ||
             (op.act == TA_ACT_PRELU && op.prelu_off < 0) || (op.out2 >= 0 && (op.scale2_off < 0 || op.shift2_off < 0)) ||
@@ -599,7 +601,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
         m->tensor_read[t] = m->tensor_read[m->tdesc[t].alias_of] = 1;
     for (auto& op : m->ops) {
       if (op.type == TA_OP_DWCONV && (m->tdesc[op.in].unscale_off >= 0 || m->tdesc[op.out].unscale_off >= 0)) bad = true;
-      if ((op.type == TA_OP_CONV || op.type == TA_OP_DWPW) && (op.prec == 3 || op.prec == 4)) m->has_half_ops = true;
+      if ((op.type == TA_OP_CONV || op.type == TA_OP_DWPW) && (op.prec == 3 || op.prec == 4 || op.prec == 5)) m->has_half_ops = true;
     }
     if (bad) {
       delete m;
@@ -723,7 +725,16 @@ int ta_model_debug_amax(ta_model* m, int enable, float* out, int capacity) {
     TA_HIP(ctx, hipMemcpy(out, slots, n * sizeof(float), hipMemcpyDeviceToHost));   // bit patterns of |x| ARE the floats
   }
   if (enable == 2) return TA_OK;                 // read only: the collection goes on
-  if (enable) TA_HIP(ctx, hipMemset(slots, 0, 2 * TA_AMAX_OPS * sizeof(unsigned)));
+  if (enable) {
+    // the slots belong to the context, the switch to the model: a second model of the same context must not zero or overwrite
+    // what the first one is collecting
+    if (ctx->amax_owner && ctx->amax_owner != m)
+      return ta_fail(ctx, TA_E_INVALID, "debug_amax: another model of this context is collecting (disable it first)");
+    TA_HIP(ctx, hipMemset(slots, 0, 2 * TA_AMAX_OPS * sizeof(unsigned)));
+    ctx->amax_owner = m;
+  } else if (ctx->amax_owner == m) {
+    ctx->amax_owner = nullptr;
+  }
   m->amax_on = enable != 0;
   return TA_OK;
 }
@@ -740,6 +751,7 @@ void ta_model_free(ta_model* m) {
   ta_enter(m ? m->ctx : nullptr);
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->ctx->amax_owner == m) m->ctx->amax_owner = nullptr;
   free_plans(m);
   if (m->weights_dev) (void)hipFree(m->weights_dev);
   delete m;

@@ -64,7 +64,7 @@ struct ta_op_desc {
   int32_t res, res_ch_off, res_up2;   // residual tensor (-1 none); res_up2: read residual at (y/2, x/2)
   int32_t out2, out2_ch_off;          // second output = out*scale2 + shift2 (-1 none)
   int32_t n_slabs;                    // K slabs of 32 floats (8 chunks of 4 channels)
-  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits), 4 = f16 (11 bits: tolerance mode)
+  int32_t prec;                       // 0 = f32 MFMA, 1 = bf16x3 split (16 bits), 2 = bf16 (throughput), 3 = f16x3 split (22 bits), 4 = f16 (11 bits: tolerance mode), 5 = f16x2 (f16x3's tensors and weights, activations enter the products as their hi half: tolerance mode)
   int32_t groups;                     // grouped conv: `cin` is per group, group g reads channels in_ch_off + g*cin
   int32_t variant;                    // bits 0..7: 0 = automatic, else the TA_CV_* kernel variant this conv MUST run on (tests);
                                       // bits 8..15: K-split factor fixed by the packer for this layer (0 = the library's rule);
@@ -151,6 +151,7 @@ struct ta_ctx {
   // the pinned host word behind the results of a call (ta_range_enqueue) and turned into TA_E_RANGE (ta_range_check)
   int* range_flag = nullptr;                       // device: [0] the flag, [TA_AMAX_SLOT0 ..] the tools' amax slots (2 per op, TA_AMAX_OPS ops)
   int* range_flag_host = nullptr;
+  const void* amax_owner = nullptr;                // tools: the ONE model of this context whose ops report into the amax slots (ta_model_debug_amax)
   // algorithmic FLOPs per dense-conv KERNEL INSTANCE ("conv_igemm_split<2,4,4,3,3>", ...) since the last reset
   // (ta_debug_kernel_work): joins a rocprofv3 per-kernel time table with the work each template instance did
   double cur_flops = 0;
@@ -178,6 +179,9 @@ enum {
   TA_CV_SPLIT_2x2_P8 = 5, // conv_igemm_split<2,2,8>: same tile, 8 producer waves
   TA_CV_SPLIT_2x4 = 6,    // conv_igemm_split<2,4,4>: 128 x 256, 8 consumer waves
   TA_CV_SPLIT_1x4 = 7,    // conv_igemm_split<1,4,4>: 64 cout x 256 px
+  TA_CV_WIN_2x2 = 8,      // conv_igemm_win<2,2>: 128 x 128, the pixel operand of a channel block resident in LDS (stride-1 convs, >= 4 taps)
+  TA_CV_WIN_2x4 = 9,      // conv_igemm_win<2,4>: 128 x 256
+  TA_CV_WIN_1x4 = 10,     // conv_igemm_win<1,4>: 64 cout x 256 px
   TA_CV_COUNT = 16
 };
 
@@ -267,6 +271,7 @@ struct ta_conv_launch {
   int res_img, res_row, res_pix, res_off0, res_up2, res_ch, res_fmt;
   int o2_img, o2_row, o2_pix, o2_off0, o2_ch, o2_fmt;
   int in_fmt;
+  int win_wp, win_img;                         // pixels per padded row / per padded image of the INPUT tensor (conv_igemm_win: patch rows)
   int direct_epilogue;                         // debug A/B: 1 = split kernel stores straight from the accumulators
   int group_cout, group_cin;                   // grouped conv: output channels / input channels per group (0 = dense)
   int k_split;                                 // > 1: K is cut in k_split ranges, one workgroup each; raw sums go to
@@ -300,7 +305,7 @@ struct ta_conv_launch {
 };
 
 // the pre-split activation format the conv kernels of arithmetic mode `prec` read (PREC_* of conv_igemm.hip)
-static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : (prec == 4 ? 3 /* TA_FMT_F16 */ : (prec == 3 ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */)); }
+static inline int ta_split_fmt_of(int prec) { return prec == 0 ? 0 /* TA_FMT_F32 */ : (prec == 4 ? 3 /* TA_FMT_F16 */ : ((prec == 3 || prec == 5) ? 2 /* TA_FMT_SPLIT16 */ : 1 /* TA_FMT_SPLIT */)); }
 
 // K-splitting of a conv with a very long K and few output tiles (ArcFace's 25088 -> 512 FC: 784 slabs, 4..8 tiles of
 // 128 x 128 at the batch sizes in use): K is cut in a FIXED number of ranges that depends on the layer only, never on
@@ -361,8 +366,7 @@ struct ta_model {
   std::vector<ta_tensor_desc> tdesc;
   std::vector<ta_op_desc> ops;
   char* weights_dev = nullptr;
-  bool has_half_ops = false;                    // any conv / dw+pw op with prec 3 / 4: every store is range-checked (ta_conv_launch::range_check)
-  float* ones_dev = nullptr;                    // [max coutp] of 1.0f: the un-scale vector of ops packed without one
+  bool has_half_ops = false;                    // any conv / dw+pw op with prec 3 / 4 / 5: every store is range-checked (ta_conv_launch::range_check)
   bool amax_on = false;                         // tools (ta_model_debug_amax): ops report the largest |x| they store into the context's slots
   std::vector<char> tensor_read;                // per tensor: some op of the program reads it (results no op reads are not range-checked)
   std::vector<std::vector<float>> unscale_host; // per tensor: host copy of its un-scale vector (empty: none)

@@ -51,19 +51,28 @@ def active_switches():
     return tuple((k, os.environ[k]) for k in PACK_SWITCHES if os.environ.get(k))
 
 
+_SOURCE_TAG = []
+
+
 def source_tag():
-    """Short hash of the packer's own sources: a repack cache written by another version of pack.py / arch.py is not read."""
-    import hashlib
-    h = hashlib.sha256()
-    here = os.path.dirname(os.path.abspath(__file__))
-    for f in ('pack.py', 'arch.py'):
-        with open(os.path.join(here, f), 'rb') as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:10]
+    """Short hash of the packer's own sources: a repack cache written by another version of pack.py / arch.py is not read.
+    Computed once per process; an install without the .py files (pyc-only, zip) falls back to the blob version alone."""
+    if not _SOURCE_TAG:
+        import hashlib
+        h = hashlib.sha256()
+        here = os.path.dirname(os.path.abspath(__file__))
+        try:
+            for f in ('pack.py', 'arch.py'):
+                with open(os.path.join(here, f), 'rb') as fh:
+                    h.update(fh.read())
+            _SOURCE_TAG.append(h.hexdigest()[:10])
+        except OSError:
+            _SOURCE_TAG.append('nosrc')
+    return _SOURCE_TAG[0]
 
 
-PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3, 'f16': 4}
-SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16, 4: FMT_F16}     # pre-split activation format per arithmetic mode
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x3': 3, 'f16': 4, 'f16x2': 5}     # 'f16x2': f16x3's tensors and weights, two of its three MFMAs per product ((w_hi + w_lo) * x_hi): embedder only
+SPLIT_FMT = {0: FMT_F32, 1: FMT_SPLIT, 2: FMT_SPLIT, 3: FMT_SPLIT16, 4: FMT_F16, 5: FMT_SPLIT16}     # pre-split activation format per arithmetic mode
 
 
 def _rup(x, m):
@@ -624,7 +633,7 @@ class Program:
         n = len(self.tensors)
         sizes = [t[0] for t in self.tensors]
         scales = [np.zeros(c, np.int64) for c in sizes]
-        if not self.scales_enabled or not any(op['type'] in (OP_CONV, OP_DWPW) and op['prec'] in (3, 4) for op in self.ops):
+        if not self.scales_enabled or not any(op['type'] in (OP_CONV, OP_DWPW) and op['prec'] in (3, 4, 5) for op in self.ops):
             return scales
         base = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         parent = np.arange(base[-1], dtype=np.int64)
@@ -706,7 +715,7 @@ class Program:
         n_slabs = flat.shape[0] // 32
         packed = fs.reshape(n_slabs, 32, coutp).transpose(0, 2, 1)          # [slab][cout][32]
         wexp = np.zeros(coutp, np.int64)
-        if op['prec'] in (3, 4):
+        if op['prec'] in (3, 4, 5):
             packed, wexp = split_f16_rows(packed)
         elif op['prec'] != 0:
             packed = split_bf16_rows(np.ascontiguousarray(packed))
@@ -834,7 +843,7 @@ OP_FEAT, OP_PAF, OP_HM, OP_XCH = 0, 128, 168, 192
 def pack_openpose(sd, precision='f32'):
     """openpose/model.py:27-141.  Stage inputs cat[PAF, HM, feat] live in two ping-pong
     192-channel tensors; every stage-output conv writes its slice directly."""
-    if precision == 'f16':            # the single-half mode is for networks without discrete decisions: pose keeps 22 bits
+    if precision in ('f16', 'f16x2'):   # the embedder's tolerance modes are for networks without discrete decisions: pose keeps 22 bits
         precision = 'f16x3'
     P = Program(MODEL_OPENPOSE, precision)
     t = P.tensor(4, 1, name='input')
@@ -1041,7 +1050,7 @@ def pack_retinaface(sd, precision='f32', fused=None):
     # order of near-tied scores in 3 % of the images.  The graph is HBM-bound (35 FLOP/B), so the exact-f32 MFMA costs
     # next to nothing here: in the `bf16x3` mode the detector runs on it, and its results ARE the `f32` mode's, bit for
     # bit.  (`bf16`, the throughput mode outside the parity bar, stays bf16.)  All activations are float32.
-    if precision == 'f16':            # the single-half mode is for networks without discrete decisions: the detector keeps 22 bits
+    if precision in ('f16', 'f16x2'):   # the embedder's tolerance modes are for networks without discrete decisions: the detector keeps 22 bits
         precision = 'f16x3'
     det_prec = 'f32' if precision in ('bf16x3', 'f16x3') else precision
     P = Program(MODEL_RETINAFACE, det_prec)

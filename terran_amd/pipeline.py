@@ -64,9 +64,24 @@ class _Embedder:
         self.ctx = runtime.new_context(self.device)
         self.rec = make_rec(self.device, self.ctx)
         self.q = queue.Queue()
+        self.upstream = 0                                   # shards uploaded on this device whose detections have not arrived here yet
+        self._up_lock = threading.Lock()
         self.launches = self.crops = 0                      # statistics: crops per launch = crops / launches
         self.thread = threading.Thread(target=self._guard, daemon=True, name='terran_amd-embed')
         self.thread.start()
+
+    def announce(self):
+        """A lane uploaded a shard: its detections WILL arrive (deliver / skip)."""
+        with self._up_lock:
+            self.upstream += 1
+
+    def deliver(self, item):
+        self.q.put(item)
+        self.skip()
+
+    def skip(self):
+        with self._up_lock:
+            self.upstream -= 1
 
     def _guard(self):
         try:
@@ -74,6 +89,13 @@ class _Embedder:
             self._loop()
         except BaseException as e:                              # noqa: BLE001  (re-raised in the consumer)
             self.fail(e)
+            while True:                                         # what is still queued keeps its frames in HBM otherwise
+                try:
+                    it = self.q.get_nowait()
+                except queue.Empty:
+                    break
+                if it is not _STOP:
+                    it[4].release()
 
     def _loop(self):
         carry = None
@@ -88,8 +110,12 @@ class _Embedder:
             while n < self.min_crops:                           # more shards, until enough crops or the wait is over
                 left = deadline - time.perf_counter()
                 try:
-                    nxt = self.q.get(timeout=left) if left > 0 else self.q.get_nowait()
+                    # nothing between upload and detect on this device (an interactive / tracking loop that feeds one batch
+                    # at a time): no more faces are coming, waiting would only add `max_wait` to every batch
+                    nxt = self.q.get(timeout=min(left, 0.001)) if left > 0 else self.q.get_nowait()
                 except queue.Empty:
+                    if left > 0 and self.upstream > 0:
+                        continue
                     break
                 if nxt is _STOP:
                     stop = True
@@ -177,6 +203,8 @@ class _Lane:
                 continue
             frames = self.ctx_up.upload(shard) if own else shard
             refs = _Refs(3, frames if (own or free_resident) else None)
+            if self.embedder is not None:
+                self.embedder.announce()
             for q in tasks:
                 q.put((gen, key, frames, refs, pick))
 
@@ -191,6 +219,7 @@ class _Lane:
                 if self.embedder is None:
                     self.q_faces.put(None)                      # keeps the embed thread's two queues in step
                 else:
+                    self.embedder.skip()
                     refs.release()
                 refs.release()
                 continue
@@ -198,8 +227,12 @@ class _Lane:
             faces = pick(dets)
             if self.embedder is None:
                 self.q_faces.put(faces)
+            elif not any(len(f) for f in faces):                # no face in the shard: nothing to wait for, nothing to launch
+                self.embedder.skip()
+                self.out_q.put((gen, key, 1, [np.empty((0, 512)) for _ in faces]))
+                refs.release()
             else:                                               # the embed worker lets go of the frames for its task
-                self.embedder.q.put((gen, key, frames, faces, refs, sum(len(f) for f in faces)))
+                self.embedder.deliver((gen, key, frames, faces, refs, sum(len(f) for f in faces)))
             self.out_q.put((gen, key, 0, dets))
             refs.release()
 

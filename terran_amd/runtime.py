@@ -63,13 +63,24 @@ def resolve_state(kind, state):
     raise ValueError('Checkpoint not found.')     # same error as terran/checkpoint.py:242,310
 
 
+DEFAULT_PRECISION = 'f16x2'
+
+
 def resolve_precision(precision=None):
-    """'f32' (exact-f32 MFMA; the parity mode), 'f16x3' (split-half MFMA: 22-bit operands, three MFMAs per product,
-    float32-grade results; half-float range, see TA_E_RANGE), 'bf16x3' (split-bf16 MFMA: 16-bit operands, float32 range)
-    or 'bf16' (throughput mode, outside the 1e-3 parity bar).  Default: $TERRAN_AMD_PRECISION or 'f16x3' (the detector is
-    exact f32 in every parity mode; ArcFace / OpenPose fall back to an exact-f32 twin on TA_E_RANGE, RangeFallback below)."""
-    p = precision or os.environ.get('TERRAN_AMD_PRECISION', 'f16x3')
-    if p not in ('f32', 'f16x3', 'bf16x3', 'bf16', 'f16'):
+    """A precision names the arithmetic of all three networks:
+      'f32'    every conv on the exact-f32 MFMA (the like-for-like arithmetic);
+      'f16x3'  split-half MFMA everywhere: operands x = hi + lo (two IEEE halfs, 22 bits), three MFMAs per product, float32-grade
+               results (the detector's raw-pixel front stays exact f32, its deep base and refiner run split-half); half-float
+               range: TA_E_RANGE -> the wrappers re-run the batch on an exact-f32 twin (RangeFallback below);
+      'f16x2'  THE DEFAULT ($TERRAN_AMD_PRECISION overrides): the detector and the pose network -- everything that takes a discrete
+               decision -- exactly as in 'f16x3' (the same packed programs, bit for bit); the embedder, whose only bar is 1e-3 on
+               the unit-norm embedding, on two of the three products, (w_hi + w_lo) * x_hi: weights and the shortcut trunk keep 22
+               bits, an activation enters a contraction as its hi half.  Measured 1.8e-4 (seeded weights) / 8.2e-4 (wild-statistics
+               weights) worst component against the oracle, cosine distance 1.6e-6 (tests/probe_embedder_modes.py);
+      'f16'    opt-in: the embedder on ONE MFMA per product and 2-byte activations (3.3e-4 / 1.8e-3: outside the bar on the wild weights);
+      'bf16x3' split-bf16 (16-bit operands, float32 range); 'bf16' throughput mode outside the 1e-3 parity bar."""
+    p = precision or os.environ.get('TERRAN_AMD_PRECISION', DEFAULT_PRECISION)
+    if p not in ('f32', 'f16x3', 'bf16x3', 'bf16', 'f16', 'f16x2'):
         raise ValueError('unknown precision %r' % (p,))
     return p
 
@@ -114,6 +125,8 @@ def packed_program(kind, state, precision):
     dict must not be mutated in place between two models built from it (copy it: `dict(sd)`)."""
     from . import checkpoint, pack
     packer = getattr(pack, 'pack_%s' % kind)
+    if kind != 'arcface' and precision in ('f16', 'f16x2'):     # the embedder's tolerance modes: detector and pose ARE the f16x3 programs
+        precision = 'f16x3'                                     # (one pack, one memo entry, one cache file for all three names)
     path = None
     if state is None:
         path = checkpoint.find_checkpoint_file(kind)
@@ -148,6 +161,14 @@ def packed_program(kind, state, precision):
     prog = packer(weights.load_state(path), precision)
     try:
         prog.save_cache(cache)
+        # repack caches of this checkpoint and precision written for another file state / blob version / packer: orphans now
+        import glob
+        for old in glob.glob('%s.%s.*.tam' % (glob.escape(os.path.splitext(str(path))[0]), precision)):
+            if old != cache:
+                try:
+                    os.unlink(old)
+                except OSError:
+                    pass
     except OSError:
         pass                                        # read-only checkpoint dir: run uncached
     return prog

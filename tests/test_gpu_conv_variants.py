@@ -251,3 +251,75 @@ def test_pinned_variant_that_cannot_run_the_layer_is_an_error(ctx):
     with pytest.raises(lib.TerranAmdError) as e:
         m.forward_frames(ctx.upload(synth.frames(1, 1, 16, 16)))
     assert e.value.code == lib.E_INVALID and 'variant' in str(e.value)
+
+
+# ---- window-resident pixel operand (conv_igemm_win): same tiles, same K order, same epilogue as the streaming split-role kernel ----
+WIN_LAYERS = {
+    # ArcFace stage 3 / stage 2 / stage 1 bodies at 64 crops; tiles cross image boundaries (196 / 784 / 3136 pixels per image)
+    'arc14_256': dict(n=64, h=14, w=14, c1=256, cout=256, k=3, act=2),
+    'arc28_128': dict(n=64, h=28, w=28, c1=128, cout=128, k=3, act=2),
+    'arc56_64': dict(n=16, h=56, w=56, c1=64, cout=64, k=3, act=2),
+    'arc14_res': dict(n=37, h=14, w=14, c1=256, cout=256, k=3, res=True),
+    # ragged: maps narrower than a tile row run, several images per tile, a last tile with a handful of pixels
+    'tiny_5x3': dict(n=41, h=5, w=3, c1=128, cout=128, k=3, act=1),
+    'tiny_2x7': dict(n=29, h=2, w=7, c1=128, cout=128, k=3, act=1),
+    # 5 x 5 (halo 2) and a grouped 3 x 3
+    'k5_16x20': dict(n=5, h=16, w=20, c1=128, cout=128, k=5, act=1),
+    'k3_grouped': dict(n=4, h=9, w=11, c1=256, cout=256, k=3, groups=2, act=1),
+    # VGG-like 3 x 3 at the 1080p pose size (23 x 40): the widest map the 128 x 256 patch capacity takes
+    'vgg23x40_256': dict(n=8, h=23, w=40, c1=256, cout=256, k=3, act=1),
+}
+WIN_CASES = [('arc14_256', '2x2'), ('arc14_256', '2x4'), ('arc28_128', '2x2'), ('arc28_128', '2x4'), ('arc56_64', '1x4'), ('arc14_res', '2x2'),
+             ('arc14_res', '2x4'), ('tiny_5x3', '2x2'), ('tiny_2x7', '2x2'), ('k5_16x20', '2x2'), ('k3_grouped', '2x2'), ('k3_grouped', '2x4'),
+             ('vgg23x40_256', '2x2'), ('vgg23x40_256', '2x4')]
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f16x2'])
+@pytest.mark.parametrize('layer,tile', WIN_CASES, ids=['%s-%s' % c for c in WIN_CASES])
+def test_window_kernel_equals_streaming_kernel(ctx, layer, tile, precision):
+    """conv_igemm_win keeps the pixel operand of a channel block resident in LDS instead of streaming it per filter tap; tile
+    mapping, K order, MFMA order and epilogue are conv_igemm_split's, so every output BIT must equal that kernel's (which the
+    tests above hold against torch).  Also: the automatic choice takes the window kernel wherever it is eligible."""
+    from terran_amd import lib
+    L = WIN_LAYERS[layer]
+    rng = np.random.default_rng(23)
+    n, h, w, c1, cout, k = L['n'], L['h'], L['w'], L['c1'], L['cout'], L['k']
+    W1, b1, W2, b2 = _weights(L, rng)
+    prelu = rng.uniform(0.1, 0.4, cout).astype(np.float32)
+    Wr, br = rng.normal(0, 0.3, (cout, 3, 3, 3)).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    fr = ctx.upload(synth.frames(6, n, h, w))
+    outs = {}
+    for variant in ('split_' + tile, 'win_' + tile, 'auto'):
+        P = pack.Program(pack.MODEL_OPENPOSE, precision)
+        t0 = P.tensor(4, 1)
+        P.input_tensor = t0
+        t1 = P.tensor(c1, k // 2, name='mid')
+        P.conv(t0, t1, W1, b1, act=pack.ACT_RELU)
+        t2 = P.tensor(cout, 1, name='out')                       # split format (a conv reads it), halo 1
+        kw = dict(variant=lib.CONV_VARIANTS[variant], groups=L.get('groups', 1), act=L.get('act', 0))
+        if L.get('act') == 2:
+            kw['prelu'] = prelu
+        if L.get('res'):
+            tres = P.tensor(cout, 0, name='res')
+            P.conv(t0, tres, Wr, br, pad=1)
+            kw['res'] = tres
+        P.conv(t1, t2, W2, b2, **kw)
+        t3 = P.tensor(32, 0, name='sink', f32=True)              # keeps `out` in the split format
+        P.conv(t2, t3, rng.normal(0, 0.05, (32, cout, 3, 3)).astype(np.float32), np.zeros(32, np.float32))
+        P.outputs = [t3]
+        m = lib.Model(ctx, P)
+        ctx.conv_counts(reset=True)
+        m.forward_frames(fr)
+        counts = ctx.conv_counts()
+        assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
+        if variant != 'auto':
+            assert counts.get(variant, 0) >= 1, (variant, counts)
+        else:
+            assert any(kname.startswith('win_') for kname in counts), counts      # eligible -> chosen
+        outs[variant] = (m.read('out'), counts)
+        m.free()
+    fr.free()
+    ref = outs['split_' + tile][0]
+    assert np.abs(ref).max() > 0
+    assert np.array_equal(outs['win_' + tile][0], ref), (layer, tile, float(np.abs(outs['win_' + tile][0] - ref).max()))
+    assert np.array_equal(outs['auto'][0], ref)

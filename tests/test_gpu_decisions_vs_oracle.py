@@ -32,8 +32,19 @@ _results = {}
 
 def rare_bound(n):
     """Upper bound for a count of rare events that is claimed to occur at the rate of a reference count `n`: n + n / 2 plus
-    two standard deviations of a Poisson count of that size (never less than 3)."""
+    two standard deviations of a Poisson count of that size (never less than 3).  For the ill-conditioned wild weights and
+    for the long counts (TA_DECISIONS_SCALE > 1) only: the benign cases at the suite's own size are held to `tight_bound`."""
     return n + max(3, n // 2 + 2 * int(np.sqrt(n)))
+
+
+def tight_bound(n):
+    """Benign weights at the suite's default size: the default mode may flip ONE near-tie more than the exact-f32 MFMA mode
+    does (measured: 0 where f32 has 0 - 2).  A doubling of the default mode's flip rate fails here."""
+    return n + 1
+
+
+def benign_bound(n):
+    return tight_bound(n) if _SCALE == 1 else rare_bound(n)
 
 
 def _record(task, mode, tot):
@@ -143,10 +154,10 @@ def test_openpose_decisions_vs_oracle(states, case):
     # the exact-f32 MFMA mode itself: a handful of near-ties per thousand decisions at most (per hundred connections on the
     # ill-conditioned wild weights, where two float32 evaluations of one network differ by more)
     assert f32['dpeaks'] <= max(3, f32['peaks'] // 1000) and f32['dhumans'] <= max(2, f32['humans'] // 100)
-    # the default mode flips near-ties at the exact-f32 mode's RATE: these are counts of rare events, so the bound is that
-    # mode's own count with half of it and two standard deviations of slack (`rare_ok`; it holds at any sample size --
-    # TA_DECISIONS_SCALE=5 measures 12 vs 15 and 21 vs 16 peaks of ~50 000 on the random frames, 0 vs 0 on the people)
-    slack = rare_bound
+    # the default mode flips near-ties at the exact-f32 mode's RATE: at the suite's size the bound is that mode's own count
+    # + 1 (`tight_bound`); the long counts (TA_DECISIONS_SCALE=5 measures 12 vs 15 and 21 vs 16 peaks of ~50 000 on the random
+    # frames, 0 vs 0 on the people) are counts of rare events and get the statistical bound (`rare_bound`)
+    slack = benign_bound
     assert head['dpeaks'] <= slack(f32['dpeaks']) and head['dconns'] <= slack(f32['dconns']) and head['dhumans'] <= slack(f32['dhumans']), table
     if 'f16' in table:                                   # the opt-in mode packs this network exactly as f16x3 does: same decisions
         assert {k: v for k, v in table['f16'].items()} == {k: v for k, v in head.items()}, table
@@ -197,7 +208,8 @@ def test_retinaface_decisions_vs_oracle(states, case):
     # disagree on ~0.5 % of the near-threshold anchors (tests/probe_wild_weights.py counts both against a float64 evaluation)
     assert f32['ddets'] <= (max(2, f32['dets'] // 1000) if not wild else max(4, f32['dets'] // 100))
     # f16x3: refiner + deep base on the split-half MFMA (bf16x3 keeps the whole detector exact f32): no worse than f32
-    assert head['ddets'] <= rare_bound(f32['ddets']) and head['images_reordered'] <= rare_bound(f32['images_reordered']), table
+    bound = rare_bound if wild else benign_bound
+    assert head['ddets'] <= bound(f32['ddets']) and head['images_reordered'] <= bound(f32['images_reordered']), table
     assert table.get('bf16x3', f32) == f32
     assert table.get('f16', head) == head                # the opt-in mode's detector IS the f16x3 program
 
@@ -214,7 +226,7 @@ def test_arcface_embeddings_vs_oracle(states, stats):
         crops[32:] = wild_weights._calib_frames(77, 32, 112, 112)[..., ::-1].transpose(0, 3, 1, 2)
     ref = arcface_pre.l2_normalize(nets.arcface_forward(sd, torch.from_numpy(crops.astype(np.float32))).numpy())
     table = {}
-    for mode in MODES:
+    for mode in MODES + ['f16x2']:
         a = ArcFace(device=0, state=sd, precision=mode)
         e = a.embed_crops(crops)
         table[mode] = dict(max_abs=float(np.abs(e - ref).max()), max_cosine_distance=float(1.0 - (e * ref).sum(1).min()),
@@ -224,6 +236,9 @@ def test_arcface_embeddings_vs_oracle(states, stats):
     assert all(t['range_fallbacks'] == 0 for t in table.values()), table
     assert table['f32']['max_abs'] < (5e-6 if stats == 'benign' else 2e-5)
     assert table[HEADLINE]['max_abs'] <= max(2 * table['f32']['max_abs'], 2e-6)
+    # the DEFAULT embedder (two of the three products: weights and trunk at 22 bits, activations enter as their hi half): inside
+    # north_star's 1e-3 on both weight sets (measured 1.8e-4 / 8.2e-4), cosine distances ~1e-6
+    assert table['f16x2']['max_abs'] <= (3e-4 if stats == 'benign' else 1e-3) and table['f16x2']['max_cosine_distance'] <= 5e-6, table
     if 'f16' in table:
         # the opt-in single-half embedder: inside north_star's 1e-3 with a 3 x margin on the benign statistics; on weights with
         # trained-looking statistics 11-bit operands measure 1.8e-3 -- OUTSIDE the bar: that mode is for checkpoints it has
@@ -398,3 +413,15 @@ def test_wild_weights_decisions_vs_float64(states):
         # slack (5 x the frames: detector 178 vs 194, pose 329 vs 256 -- connection flips come in clusters; tests/probe_map_error.py: the maps
         # themselves are as close to float64 in f16x3 as in f32)
         assert head['flips'] <= rare_bound(f32['flips']), rows
+
+
+def test_pooled_benign_flip_count():
+    """All benign-weight cases of this file pooled: the default mode's near-tie flips against the oracle do not exceed the
+    exact-f32 MFMA mode's by more than two over ~100 000 decisions (per-case slack does not add up)."""
+    keys = ('dpeaks', 'dconns', 'dhumans', 'ddets', 'images_reordered')
+    rows = {k: v for k, v in _results.items() if k.startswith(('openpose_', 'retinaface_')) and 'f32' in v and HEADLINE in v}
+    if len(rows) < 4:
+        pytest.skip('the per-case tests of this file did not run in this session')
+    tot = {m: sum(v[m].get(k, 0) for v in rows.values() for k in keys) for m in ('f32', HEADLINE)}
+    print('pooled flips vs oracle over %d cases: %s' % (len(rows), tot))
+    assert tot[HEADLINE] <= (tot['f32'] + 2 if _SCALE == 1 else rare_bound(tot['f32'])), (tot, rows)

@@ -89,7 +89,7 @@ def test_range_flag_is_raised_by_the_epilogue_and_cleared(ctx):
         assert _forward_checked(ctx, lib.Model(ctx, _two_convs(prec, 2.0 ** 20)), frames) == lib.OK
 
 
-@pytest.mark.parametrize('mode', ['f16x3', 'f16'])
+@pytest.mark.parametrize('mode', ['f16x3', 'f16', 'f16x2'])
 def test_split_role_epilogues_raise_the_flag(ctx, mode):
     """The lean (conv_drain_fast) and the generic LDS-staged drains of the split-role kernel: a 64 -> 64 conv whose
     OUTPUT is a split tensor stored 2^14 beyond the range its weights predict (forced_scale)."""
@@ -216,7 +216,7 @@ def test_openpose_wrapper_falls_back_to_f32(states, monkeypatch):
     assert c.fallbacks == 0
 
 
-@pytest.mark.parametrize('mode', ['f16x3', 'f16'])
+@pytest.mark.parametrize('mode', ['f16x3', 'f16', 'f16x2'])
 def test_arcface_wrapper_falls_back_to_f32(states, mode, monkeypatch):
     from terran_amd import ArcFace
     sd = dict(states('arcface'))
@@ -231,7 +231,7 @@ def test_arcface_wrapper_falls_back_to_f32(states, mode, monkeypatch):
     eb = b.embed_crops(crops)
     s = ArcFace(device=0, state=sd, precision=mode)               # activation scales: runs as it is
     es = s.embed_crops(crops)
-    assert s.fallbacks == 0 and np.abs(es - eb).max() < (1e-3 if mode == 'f16' else 2e-6)
+    assert s.fallbacks == 0 and np.abs(es - eb).max() < (1e-3 if mode in ('f16', 'f16x2') else 2e-6)
     _no_scales(monkeypatch)
     a = ArcFace(device=0, state=sd, precision=mode)
     ea = a.embed_crops(crops)

@@ -11,7 +11,7 @@ from terran_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3', 'f16'])     # 'f16': the opt-in single-half embedder (detector / pose = f16x3)
+@pytest.fixture(scope='module', params=['f32', 'f16x3', 'bf16x3', 'f16', 'f16x2'])     # 'f16': the opt-in single-half embedder (detector / pose = f16x3)
 def precision(request):
     return request.param
 
@@ -123,8 +123,8 @@ def _rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
 
 
-NET_TOL = {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 1e-4, 'f16': 2e-5}      # f16: detector and pose network ARE the f16x3 programs
-EMB_TOL = {'f32': (2e-5, 5e-6), 'f16x3': (2e-5, 5e-6), 'bf16x3': (2e-4, 5e-5), 'f16': (5e-3, 1e-3)}   # (raw rel, unit abs); f16: north_star's 1e-3
+NET_TOL = {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 1e-4, 'f16': 2e-5, 'f16x2': 2e-5}      # f16: detector and pose network ARE the f16x3 programs
+EMB_TOL = {'f32': (2e-5, 5e-6), 'f16x3': (2e-5, 5e-6), 'bf16x3': (2e-4, 5e-5), 'f16': (5e-3, 1e-3), 'f16x2': (2e-3, 4e-4)}   # (raw rel, unit abs); f16: north_star's 1e-3
 
 
 def test_c2_fullsize_image_vs_oracle(states, precision):
@@ -264,7 +264,7 @@ def test_c5_fullsize_frame_vs_oracle(states, precision):
     # what this frame measures: the default mode (and the opt-in 'f16', whose detector is the same program) reproduces the
     # oracle's list position by position; the exact-f32 detector ('f32', 'bf16x3') has 4 of its 372 near-tied scores in
     # swapped order -- the slack above is what two float32 implementations MAY do, the bound below what they DO
-    assert n_off == 0 and n_swapped <= (0 if precision in ('f16x3', 'f16') else 6), (n_swapped, n_off)
+    assert n_off == 0 and n_swapped <= (0 if precision in ('f16x3', 'f16', 'f16x2') else 6), (n_swapped, n_off)
     err = float(np.abs(feats - r_feats).max())
     assert len(poses) == len(r_poses) >= 3
     for a, b in zip(poses, r_poses):

@@ -251,13 +251,13 @@ def test_worksize_nets_vs_reference_goldens(ctx, states, precision):
     m.free()
 
 
-@pytest.mark.parametrize('precision', PRECISIONS + ['f16'])
+@pytest.mark.parametrize('precision', PRECISIONS + ['f16', 'f16x2'])
 def test_wild_statistics_nets_vs_reference_goldens(ctx, states, precision):
     """The device on weights with trained-looking statistics against the REFERENCE modules run on the same weights
     (tests/golden/wild_*.npz).  'f16' = the opt-in single-half embedder: measured outside north_star's 1e-3 on these weights
     (DESIGN section 4), held to 5e-3 here; its detector / pose programs are f16x3's."""
     from terran_amd import lib
-    _prec[0] = 'f16x3' if precision == 'f16' else precision
+    _prec[0] = 'f16x3' if precision in ('f16', 'f16x2') else precision
     wt = {'f32': 3e-4, 'f16x3': 3e-4, 'bf16x3': 1e-3}[_prec[0]]      # ill-conditioned weights: measured 1.0e-4 (fg prob, stride 8) in the
                                                                      # exact-f32 mode and in f16x3 alike, ~5 x the benign nets' distance
     g = golden('wild_retinaface.npz')
@@ -284,10 +284,10 @@ def test_wild_statistics_nets_vs_reference_goldens(ctx, states, precision):
     m = lib.Model(ctx, pack.pack_arcface(states('wild_arcface'), precision))
     m.forward_crops(g['crops'])
     out = m.read('embedding')[:, :, 0, 0]
-    _close(out, g['embeddings'], tol=2e-2 if precision == 'f16' else wt, what='wild golden embedding')
+    _close(out, g['embeddings'], tol=2e-2 if precision in ('f16', 'f16x2') else wt, what='wild golden embedding')
     unit = lambda e: e / np.sqrt((e.astype(np.float64) ** 2).sum(1, keepdims=True))
     err = float(np.abs(unit(out) - unit(g['embeddings'])).max())
     print('  wild arcface %s: unit embeddings max abs err %.2e' % (precision, err))
-    assert err <= {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 2e-4, 'f16': 5e-3}[precision]
+    assert err <= {'f32': 2e-5, 'f16x3': 2e-5, 'bf16x3': 2e-4, 'f16': 5e-3, 'f16x2': 1e-3}[precision]      # f16x2 (the default embedder): INSIDE north_star's bar on these weights too
     assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
     m.free()

@@ -432,6 +432,31 @@ def test_f16_mode_packs_half_float_tensors_and_64_channel_slabs():
         assert packer(state, 'f16').blob() == packer(state, 'f16x3').blob()    # the SAME programs: every decision as in f16x3
 
 
+def test_f16x2_mode_is_the_f16x3_image_with_another_opcode():
+    """precision='f16x2' (the default embedder): tensors, formats, scales and every weight byte of ArcFace are f16x3's -- the
+    kernels just skip the w_hi * x_lo product -- only the ops' `prec` field differs; the detector / pose packers read the
+    mode as 'f16x3' (the same programs bit for bit), and it is what `resolve_precision()` returns by default."""
+    from terran_amd import pack, runtime, weights
+    sd = weights.make_arcface_state()
+    P2, P3 = pack.pack_arcface(sd, 'f16x2'), pack.pack_arcface(sd, 'f16x3')
+    assert {op['prec'] for op in P2.ops} == {5} and {op['prec'] for op in P3.ops} == {3}
+    assert P2.tensor_formats() == P3.tensor_formats()
+    b2, b3 = np.frombuffer(P2.blob(), np.uint8), np.frombuffer(P3.blob(), np.uint8)
+    assert len(b2) == len(b3)
+    hdr = np.frombuffer(P2.blob()[:pack.HEADER_DT.itemsize], pack.HEADER_DT)[0]
+    o0, n = int(hdr['ops_off']), len(P2.ops) * pack.OP_DT.itemsize
+    diff = np.nonzero(b2 != b3)[0]
+    assert len(diff) == len(P2.ops) and ((diff >= o0) & (diff < o0 + n)).all()      # one byte per op: its arithmetic mode
+    ops2 = np.frombuffer(P2.blob()[o0:o0 + n], pack.OP_DT)
+    assert set(ops2['prec'].tolist()) == {5}
+    for packer, state in ((pack.pack_retinaface, weights.make_retinaface_state()), (pack.pack_openpose, weights.make_openpose_state())):
+        assert packer(state, 'f16x2').blob() == packer(state, 'f16x3').blob()
+    assert runtime.DEFAULT_PRECISION == 'f16x2' and runtime.resolve_precision('f16x3') == 'f16x3'
+    import os
+    if not os.environ.get('TERRAN_AMD_PRECISION'):
+        assert runtime.resolve_precision() == 'f16x2'
+
+
 def test_activation_scales_follow_the_expected_magnitudes():
     """pack.Program: per-channel (mean, variance) are propagated through the folded weights (Gaussian moments through ReLU /
     PReLU) and every tensor of a program with half-float convs is stored times 2^a with its expected max |x| 2^a in

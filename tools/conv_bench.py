@@ -19,6 +19,7 @@ SHAPES = [
     ('pose 7x7 2x(128->128) grouped @32x23x40', 32, 23, 40, 256, 256, 7, 2),
     ('pose 7x7 2x(128->128) grouped @16x46x82', 16, 46, 82, 256, 256, 7, 2),
     ('arc  3x3 256->256 @64x14x14', 64, 14, 14, 256, 256, 3, 1),
+    ('arc  3x3 256->256 @256x14x14', 256, 14, 14, 256, 256, 3, 1),
     ('arc  3x3 128->128 @64x28x28', 64, 28, 28, 128, 128, 3, 1),
     ('arc  3x3 64->64 @64x56x56', 64, 56, 56, 64, 64, 3, 1),
     ('pose 3x3 256->256 @32x46x81', 32, 46, 81, 256, 256, 3, 1),
