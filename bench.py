@@ -87,6 +87,53 @@ DTYPES = {'f32': 'f32',
 KLASSES = ('conv_igemm', 'dw_pool_copy', 'preprocess', 'postprocess')
 
 
+def _inst_factor(precision, name):
+    """MFMAs per product of a kernel instance: PREC_F16X2 (template argument 5) instances are the embedder's two-product kernels."""
+    if precision == 'f32':
+        return 1
+    a = name[name.index('<') + 1:name.rindex('>')].split(',') if '<' in name else []
+    if name.startswith('conv_igemm_split') and len(a) > 3:
+        prec = a[3]
+    elif name.startswith('conv_igemm_win') and len(a) > 2:
+        prec = a[2]
+    elif name.startswith('conv_igemm_pipe') and len(a) > 4:
+        prec = a[4]
+    elif name.startswith(('conv_igemm<', 'conv_dwpw')) and len(a) > 4:
+        prec = a[4]
+    else:
+        prec = ''
+    return {'0': 1.0 / 16, '1': 3, '2': 1, '3': 3, '4': 1, '5': 2}.get(prec.strip(), 3)     # (an exact-f32 op inside a 16-bit program: 1/16 of an f16 MFMA's FLOPs)
+
+
+def issued_mfma_frac(precision, instances):
+    """MFMA FLOPs ISSUED (algorithmic FLOPs x products per term of each instance) per second of the profiled serial step's conv time,
+    over the dense f16 / bf16 peak: the modes that mix two- and three-product kernels have no single factor."""
+    ms = sum(v[2] for v in instances.values()) if instances else 0.0
+    if precision == 'f32' or ms <= 0:
+        return None
+    issued = sum(v[1] * _inst_factor(precision, k) for k, v in instances.items() if _inst_factor(precision, k) >= 1)
+    return round(issued / (ms * 1e-3) / 1e12 / PEAKS[precision][0], 4)
+
+
+def dominant_kernel(precision, instances):
+    """The dense-conv kernel INSTANCE with the most HIP-event time in the profiled serial step: algorithmic FLOPs per launch over its
+    average launch duration, against the dense MFMA peak of the opcode (`roofline.dominant`; the rocprofv3 table of the same
+    command, profiles/r05_<mode>_kernel_stats.csv, carries the same instance with the profiler's own durations)."""
+    if not instances:
+        return None
+    name, (n, fl, ms) = max(instances.items(), key=lambda kv: kv[1][2])
+    if ms <= 0 or n <= 0:
+        return None
+    peak = PEAKS[precision][0]
+    tf = fl / (ms * 1e-3) / 1e12
+    factor = _inst_factor(precision, name)
+    total_ms = sum(v[2] for v in instances.values())
+    return {'kernel': name, 'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 2),
+            'achieved': round(tf, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
+            'mfma_issue_frac': round(tf * factor / peak, 4), 'share_of_conv_time': round(ms / total_ms, 3),
+            'source': 'driver-run: HIP events around every launch of this instance in one serial step of this very process'}
+
+
 def conv_roofline(precision, conv):
     """`conv` = {'ms','launches','work'} of the implicit-GEMM kernels from HIP events on their launch streams."""
     achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
@@ -175,7 +222,7 @@ def main():
     ap.add_argument('--lane-embedders', action='store_true',
                     help='A/B: one embed thread + ArcFace model per lane (64 crops per launch) instead of one embed worker per '
                          'device that launches on the faces of several batches')
-    ap.add_argument('--embed-min-crops', type=int, default=256, help='embed worker: launch once this many faces are waiting ...')
+    ap.add_argument('--embed-min-crops', type=int, default=320, help='embed worker: launch once this many faces are waiting ...')
     ap.add_argument('--embed-max-crops', type=int, default=512, help='... on at most this many ...')
     ap.add_argument('--embed-max-wait', type=float, default=0.020, help='... or this many seconds after the first of them arrived')
     ap.add_argument('--single-process', action='store_true',
@@ -185,6 +232,7 @@ def main():
     args.side = not (args.single_mode or args.no_side_legs)
 
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')     # before torch initialises HIP: see terran_amd/lib.py:load
+    os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')  # likewise (kernel arguments in device memory)
     # stdout carries exactly ONE line (the JSON): everything libraries print to fd 1 (RCCL's version banner, for
     # one) is sent to stderr instead, and the result is written to the saved descriptor at the end.
     sys.stdout.flush()
@@ -475,6 +523,7 @@ def run(args):
         for c in p0.ctxs:
             c.profile_reset()
             c.profile(True)
+        before = [c.kernel_work() for c in p0.ctxs]
         p0.serial_step()
         klass = {}
         for k, name in enumerate(KLASSES):
@@ -485,6 +534,16 @@ def run(args):
             klass[name] = {'ms': round(ms, 3), 'launches': n, 'work': work}
         for c in p0.ctxs:
             c.profile(False)
+        # the same step per dense-conv KERNEL INSTANCE (launches, algorithmic FLOPs, HIP-event time): `roofline.dominant`
+        inst = {}
+        for c, w0 in zip(p0.ctxs, before):
+            for name, (n1, f1, m1) in c.kernel_work().items():
+                n0, f0, m0 = w0.get(name, (0, 0.0, 0.0))
+                a = inst.setdefault(name, [0, 0.0, 0.0])
+                a[0] += n1 - n0
+                a[1] += f1 - f0
+                a[2] += m1 - m0
+        klass['instances'] = {k: v for k, v in inst.items() if v[0] > 0}
         return klass
 
     def run_mode(precision, steps, extra=None, min_seconds=0.0):
@@ -785,16 +844,17 @@ def run(args):
                                    'batches at once (>= %d crops or %.0f ms; %.0f crops per launch measured)'
                                    % (args.embed_min_crops, args.embed_max_wait * 1e3, head.get('crops_per_embed_launch', 0))),
             },
-            'roofline': dict(conv_roofline(primary, klass['conv_igemm']),
+            'roofline': dict(conv_roofline(primary, klass['conv_igemm']), dominant=dominant_kernel(primary, klass.get('instances')),
+                             mfma_issue_frac_by_instance=issued_mfma_frac(primary, klass.get('instances')),
                              # the same algorithmic FLOPs over the PIPELINED step (what `value` is made of): above the serial
                              # figure because concurrent streams fill the CUs one kernel's tail and launch gaps leave idle
                              pipelined_achieved=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12, 2),
                              pipelined_frac=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12 / PEAKS[primary][0], 4)),
-            'stage_ms_per_step': {k: v['ms'] for k, v in klass.items()},
+            'stage_ms_per_step': {k: v['ms'] for k, v in klass.items() if k != 'instances'},
             # algorithmic bytes / kernel time of the HBM-bound kernel classes (peak 8000 GB/s); post-processing
             # mixes the pose-map stream with latency-bound selection / grouping kernels
             'stage_hbm_gbps': {k: round(v['work'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in klass.items()
-                               if k != 'conv_igemm' and v['ms'] > 0},
+                               if k not in ('conv_igemm', 'instances') and v['ms'] > 0},
         }
         if args.serial:
             # --serial is the mode the rocprofv3 kernel statistics under profiles/ are taken in: the algorithmic FLOPs every
@@ -802,7 +862,7 @@ def run(args):
             # profiler's per-kernel time table turns into TFLOP/s per template instance (profiles/summarize_round.py)
             work = {}
             for c in pipes[0].ctxs:
-                for name, (n_, fl) in c.kernel_work().items():
+                for name, (n_, fl, _ms) in c.kernel_work().items():
                     a_, b_ = work.get(name, (0, 0.0))
                     work[name] = (a_ + n_, b_ + fl)
             result['kernel_work_run'] = {k_: {'launches': v[0], 'gflop': round(v[1] / 1e9, 2)} for k_, v in sorted(work.items())}

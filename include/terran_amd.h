@@ -224,8 +224,8 @@ int ta_debug_conv_variant(ta_ctx* ctx, int variant);
  * and report whether an epilogue met |x| > 65504: TA_OK or TA_E_RANGE.  Clears the condition. */
 int ta_debug_range_check(ta_ctx* ctx);
 int ta_debug_conv_counts(ta_ctx* ctx, int64_t* counts16, int reset);
-/* Algorithmic FLOPs per dense-conv kernel INSTANCE since the last reset, as text: one "name;launches;flops" line per
- * template instance (the names rocprofv3 prints, without spaces: conv_igemm_split<2,4,4,3,3>).  Lets a per-kernel time
+/* Algorithmic FLOPs per dense-conv kernel INSTANCE since the last reset, as text: one "name;launches;flops;ms" line per
+ * template instance (ms: HIP-event time of the launches made while ta_ctx_profile was on) (the names rocprofv3 prints, without spaces: conv_igemm_split<2,4,4,3,3>).  Lets a per-kernel time
  * table from a profiler be turned into TFLOP/s per instance (profiles/summarize_round.py).  TA_E_CAPACITY if too small. */
 int ta_debug_kernel_work(ta_ctx* ctx, char* csv, size_t capacity, int reset);
 

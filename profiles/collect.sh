@@ -9,11 +9,15 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err
 SER="--steps 3 --warmup 1 --serial --no-cpu-baseline --single-mode"
-for P in f16 f16x3 f32; do
+for P in f16x2 f16x3 f32; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_$P -o k -- python $R/bench.py $SER --precision $P > $O/kt_$P.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES; do
     timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${C}_$P -o c -- python $R/bench.py --steps 1 --warmup 1 --serial --no-cpu-baseline --single-mode --precision $P > $O/pmc_${C}_$P.log 2>&1
   done
+done
+# the detector alone at C2 (32 x 640 x 640): HBM-side bytes per kernel
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_det_$C -o c -- python $R/tools/detector_profile.py 32 640 640 f16x3 > $O/pmc_det_$C.log 2>&1
 done
 # the pipelined headline under a kernel trace: how much of the timed region has 0 / 1 / 2 / 3+ kernels in flight
 timeout 600 rocprofv3 --kernel-trace -d $O/kt_pipelined -o k -- python $R/bench.py --steps 60 --warmup 6 --no-cpu-baseline --single-mode > $O/kt_pipelined.log 2>&1

@@ -69,7 +69,9 @@ def pmc_total(db_path, counter):
 
 
 def main(collect, prefix, steps=3):
-    for P in ('f16', 'f16x3', 'f32'):
+    for P in ('f16x2', 'f16', 'f16x3', 'f32'):
+        if not os.path.isdir(os.path.join(collect, 'kt_' + P)):
+            continue
         kt = find_db(os.path.join(collect, 'kt_' + P))
         out = {}
         if kt:
@@ -103,5 +105,33 @@ def main(collect, prefix, steps=3):
         print(P, json.dumps(res))
 
 
+def detector_table(collect, prefix, forwards=3):
+    """Per kernel of ONE detector forward at C2 (tools/detector_profile.py 32 640 640, the last of its `forwards` passes): HBM-side
+    bytes read (FETCH_SIZE, KiB, doubled per the gfx950 note of MI355X_MICROARCH.md) and written (WRITE_SIZE), separate --pmc passes,
+    in launch order -> <prefix>_pmc_detector.json.  `algorithmic` = SURVEY.md 8(d)'s 56.3 MB per image."""
+    rows = {}
+    for C in ('FETCH_SIZE', 'WRITE_SIZE'):
+        db = find_db(os.path.join(collect, 'pmc_det_' + C))
+        if not db:
+            return
+        cur = sqlite3.connect(db).cursor()
+        r = cur.execute('select dispatch_id, kernel_name, value, duration from counters_collection where counter_name=? order by dispatch_id', (C,)).fetchall()
+        r = [x for x in r if 'conv_' in x[1] or 'rf_' in x[1] or 'dwconv' in x[1] or 'maxpool' in x[1] or 'copych' in x[1]]
+        per = len(r) // forwards
+        rows[C] = r[-per:]
+    ops = []
+    for (d0, name, f, dur), (_, name2, w, _) in zip(rows['FETCH_SIZE'], rows['WRITE_SIZE']):
+        assert _norm(name) == _norm(name2)
+        ops.append({'kernel': _norm(name), 'us': round(dur / 1e3, 1), 'read_mb': round(2.0 * f * 1024 / 1e6, 2), 'write_mb': round(w * 1024 / 1e6, 2)})
+    tot_r, tot_w, tot_us = sum(o['read_mb'] for o in ops), sum(o['write_mb'] for o in ops), sum(o['us'] for o in ops)
+    res = {'what': 'RetinaFace forward at C2 (32 x 640 x 640, f16x3 program), one pass, kernels in launch order; the durations come from the '
+                   'counter passes (serialised dispatches, slower than an un-profiled run)',
+           'ops': ops, 'total_read_mb': round(tot_r, 1), 'total_write_mb': round(tot_w, 1), 'total_us_under_pmc': round(tot_us, 1),
+           'algorithmic_mb': round(32 * 56.3 + 0.84, 1), 'traffic_over_algorithmic': round((tot_r + tot_w) / (32 * 56.3 + 0.84), 3)}
+    json.dump(res, open(prefix + '_pmc_detector.json', 'w'), indent=1)
+    print('detector', json.dumps({k: v for k, v in res.items() if k != 'ops'}))
+
+
 if __name__ == '__main__':
     main(sys.argv[1], sys.argv[2])
+    detector_table(sys.argv[1], sys.argv[2])

@@ -30,9 +30,10 @@
 #ifdef TA_CONV_TRACE
 // Debug build only (TA_EXTRA_FLAGS=-DTA_CONV_TRACE): cycle stamps of workgroup 0 of the split kernel.
 __device__ long long ta_trace_buf[64];
+// which workgroup is stamped: TA_CONV_PROBE >> 8 (0 = the first one, which starts on an idle chip; a middle block sees the loaded one)
 #define TA_STAMP(i)                                                              \
   do {                                                                           \
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) ta_trace_buf[(i)] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == (unsigned)(p.probe >> 8) && (threadIdx.x & 63) == 0) ta_trace_buf[(i)] = __builtin_readcyclecounter(); \
   } while (0)
 extern "C" int ta_debug_trace_read(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ta_trace_buf), sizeof(long long) * n);
@@ -1762,6 +1763,8 @@ __global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_ig
   const int HoWo = p.Ho * p.Wo;
   const int S = p.n_slabs;
   const int T = p.k_w * p.k_h;                   // slabs per channel block
+  if (wave == 0) TA_STAMP(0);                       // consumer entry (tile decoded)
+  if (wave == NC) TA_STAMP(8);                      // producer entry
   // padded-raster index of a pixel's tap (0, 0) relative to the tile's first pixel: the patch row it reads at that tap
   const ta_pixel_walk walk(p, pt0, HoWo);
   const int wp = p.win_wp, wimg = p.win_img;    // pixels per padded row / per padded image (launcher)
@@ -1803,8 +1806,10 @@ __global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_ig
 #pragma unroll
       for (int i = 0; i < NPW; ++i) ta_dma16(b_base + (size_t)cb * 128, p_off[i], dst + (i * NP + pw) * 256);
     };
+    if (wave == NC) TA_STAMP(9);                    // producer: addresses ready, first weight rows issued
     issue_patch(0);
     if (S > 1) issue_a(1);
+    if (wave == NC) TA_STAMP(10);                   // producer: patch 0 + second weight slab issued
     int stage = 2, t = 0, cb = 0;
     bool patch_behind = false;                      // a patch was issued right after the previous barrier
     for (int g = 0; g < S; ++g) {
@@ -1920,8 +1925,10 @@ __global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_ig
   int kx = 0, ky = 0, cb = 0, tap_off = 0, stage = 0;
   Frag F0, F1;
   baddr(0, 0);
+  if (wave == 0) TA_STAMP(1);                       // consumer: set up, waiting for slab 0
   __builtin_amdgcn_s_barrier();                     // B_0
   asm volatile("" ::: "memory");
+  if (wave == 0) TA_STAMP(2);                       // consumer: slab 0 + patch 0 landed
   load(F0, lds, 0);
   for (int g = 0; g + 1 < S; ++g) {
     const float* st = lds + stage * A_STAGE;
@@ -1954,16 +1961,21 @@ __global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_ig
   load(F1, lds + stage * A_STAGE, 1);
   mma(F0);
   mma(F1);
+  if (wave == 0) TA_STAMP(3);                       // consumer: main loop done (last MFMAs issued)
   {
     __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: ring and patches can be reused
     asm volatile("" ::: "memory");
+    if (wave == 0) TA_STAMP(5);
     conv_epilogue_park<BN>(acc, lds, cm, cn, lane);
+    if (wave == 0) TA_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // E1: tile parked
     asm volatile("" ::: "memory");
+    if (wave == 0) TA_STAMP(7);
     if (!conv_drain_dispatch<BN, BM, 64 * (NC + NP), 1>(p, lds, ct0, pt0, tid, HoWo))
       conv_epilogue_drain<BN, BM, 64 * (NC + NP)>(p, lds, ct0, pt0, tid, HoWo, 0);
   }
+  if (wave == 0) TA_STAMP(4);                       // consumer: epilogue stores issued
 }
 
 // Second pass of a K-split conv: out = act(sum_k partial[k] + bias), ranges added in ascending order (deterministic).
@@ -2363,11 +2375,16 @@ int ta_debug_kernel_work(ta_ctx* ctx, char* csv, size_t capacity, int reset) {
   if (!ctx || (!csv && capacity)) return TA_E_INVALID;
   std::string out;
   for (const auto& kv : ctx->kernel_work) {
-    char line[160];
-    snprintf(line, sizeof(line), "%s;%lld;%.6e\n", kv.first.c_str(), (long long)kv.second.first, kv.second.second);
+    char line[200];
+    const auto t = ctx->kernel_ms.find(kv.first);
+    snprintf(line, sizeof(line), "%s;%lld;%.6e;%.6f\n", kv.first.c_str(), (long long)kv.second.first, kv.second.second,
+             t == ctx->kernel_ms.end() ? 0.0 : t->second);
     out += line;
   }
-  if (reset) ctx->kernel_work.clear();
+  if (reset && ctx->pending.empty()) {               // (pending events point at the keys)
+    ctx->kernel_work.clear();
+    ctx->kernel_ms.clear();
+  }
   if (out.size() + 1 > capacity) return ta_fail(ctx, TA_E_CAPACITY, "kernel_work: %zu bytes needed", out.size() + 1);
   memcpy(csv, out.c_str(), out.size() + 1);
   return TA_OK;

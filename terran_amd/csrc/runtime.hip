@@ -89,7 +89,8 @@ ta_prof_scope::ta_prof_scope(ta_ctx* c, int k, double w) : ctx(c), klass(k), wor
 ta_prof_scope::~ta_prof_scope() {
   if (!ctx->profiling || !a || !b) return;
   (void)hipEventRecord(b, ctx->stream);
-  ctx->pending.push_back({a, b, klass});
+  ctx->pending.push_back({a, b, klass, ctx->cur_kernel});
+  ctx->cur_kernel = nullptr;
   ctx->prof[klass].launches += 1;
   ctx->prof[klass].work += work;
 }
@@ -99,7 +100,10 @@ static void drain_profile(ta_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& pe : ctx->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) ctx->prof[pe.klass].ms += ms;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+      ctx->prof[pe.klass].ms += ms;
+      if (pe.kernel) ctx->kernel_ms[*pe.kernel] += ms;
+    }
     ctx->event_pool.push_back(pe.a);
     ctx->event_pool.push_back(pe.b);
   }
@@ -153,7 +157,7 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   *ctx->range_flag_host = 0;
   // measurement aids for tools/ (the shipped path leaves both unset)
   if (const char* e = getenv("TA_CONV_PREFER")) ctx->conv_force = atoi(e);
-#ifdef TA_TOOLS   // timing ablations that give WRONG results: only in a tools build (TA_EXTRA_FLAGS=-DTA_TOOLS), never in the shipped library
+#if defined(TA_TOOLS) || defined(TA_CONV_TRACE)   // timing ablations that give WRONG results (bits 0..7; bits 8.. = the workgroup the trace build stamps): only in a tools build (TA_EXTRA_FLAGS=-DTA_TOOLS), never in the shipped library
   if (const char* e = getenv("TA_CONV_PROBE")) ctx->conv_probe = atoi(e);
 #endif
   *out = ctx;

@@ -98,6 +98,7 @@ struct ta_prof_class {
 struct ta_pending_event {
   hipEvent_t a, b;
   int klass;
+  const std::string* kernel;   // the dense-conv kernel instance launched inside the scope (nullptr: none); a key of ta_ctx::kernel_work
 };
 
 struct ta_ctx {
@@ -156,10 +157,13 @@ struct ta_ctx {
   // (ta_debug_kernel_work): joins a rocprofv3 per-kernel time table with the work each template instance did
   double cur_flops = 0;
   std::map<std::string, std::pair<int64_t, double>> kernel_work;
+  std::map<std::string, double> kernel_ms;        // HIP-event time per instance, while profiling (the launches ta_prof_scope brackets)
+  const std::string* cur_kernel = nullptr;        // instance of the launch in flight inside the current profiling scope
   void note_kernel(const char* name) {
-    auto& e = kernel_work[name];
-    e.first += 1;
-    e.second += cur_flops;
+    auto it = kernel_work.try_emplace(name, 0, 0.0).first;      // (node keys are stable: pending events keep the pointer)
+    it->second.first += 1;
+    it->second.second += cur_flops;
+    cur_kernel = &it->first;
   }
 };
 void ta_pose_free_big(ta_ctx* ctx);  // frees pose_dbg.over

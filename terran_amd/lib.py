@@ -115,6 +115,9 @@ def load():
         # each other.  12 queues measured +3 % on the 1080p pipeline (16 streams).  Only a default: the user's setting wins,
         # and it has no effect when the HIP runtime was initialised before this library was loaded.
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
+        # kernel-argument blocks in device memory instead of host-coherent memory: a conv workgroup's first instruction is the
+        # fetch of its 400-byte launch record (~2 000 cycles from host memory; ArcFace at 64 crops 4.84 -> 4.67 ms)
+        os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
         lib = C.CDLL(LIB_PATH)
         missing = []
         for name, (res, args) in SIGNATURES.items():
@@ -229,13 +232,14 @@ class Context:
         return out
 
     def kernel_work(self, reset=False):
-        """{kernel instance name: (launches, algorithmic FLOPs)} of the dense-conv kernels since the last reset."""
+        """{kernel instance name: (launches, algorithmic FLOPs, HIP-event ms)} of the dense-conv kernels since the last reset; the
+        time covers the launches made while `profile(True)` was on (0.0 otherwise)."""
         buf = C.create_string_buffer(1 << 16)
         self.check(self.lib.ta_debug_kernel_work(self.h, buf, len(buf), int(reset)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, n, fl = line.split(';')
-            out[name] = (int(n), float(fl))
+            f = line.split(';')
+            out[f[0]] = (int(f[1]), float(f[2]), float(f[3]) if len(f) > 3 else 0.0)
         return out
 
     def pose_debug(self, n, cap_peaks=1024, cap_conn=1024):

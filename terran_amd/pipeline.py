@@ -15,8 +15,8 @@ b % inflight of that device; every lane works its shards in order.
 
 Embedding: the reference's loop is ONE loop, so one embedder sees every face of the video.  Per device a single EMBED
 WORKER (own context + ArcFace model) takes the detections of all lanes and launches on the faces of several batches at
-once (>= `embed_min_crops`, bounded wait `embed_max_wait`): ArcFace's 14 x 14 / 7 x 7 layers fill the chip at ~256 crops,
-not at the 64 one batch brings.  A face's embedding does not depend on the launch it rides in (every conv sums in a
+once (>= `embed_min_crops`, bounded wait `embed_max_wait`): ArcFace's 14 x 14 / 7 x 7 layers fill the chip's 256 CUs in whole
+rounds at 320 crops (stage 3: 490 tiles of 128 x 256 pixels; 392 at 256 crops = 1.5 rounds), not at the 64 one batch brings.  A face's embedding does not depend on the launch it rides in (every conv sums in a
 batch-independent order), so this changes no bit of any result.  `shared_embedder=False` keeps one embed thread per lane.
 
 A collector hands out (detections, features, poses) per batch in batch order, each concatenated over the devices in
@@ -294,7 +294,7 @@ class StreamPipeline:
     """
 
     def __init__(self, devices, inflight=2, depth=2, pick_faces=all_faces, detection_kw=None, recognition_kw=None,
-                 estimation_kw=None, switch_interval=2e-4, shared_embedder=True, embed_min_crops=256, embed_max_crops=512,
+                 estimation_kw=None, switch_interval=2e-4, shared_embedder=True, embed_min_crops=320, embed_max_crops=512,
                  embed_max_wait=0.020):
         """switch_interval: the lanes' threads spend their time inside GIL-free library calls; one that comes back must not
         wait a whole 5 ms interpreter time slice behind another thread's result handling before it can queue its next

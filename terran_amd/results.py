@@ -1,10 +1,20 @@
 """The reference's list-of-dicts return type over the packed result arrays of the C ABI.
 
 `detections(counts, boxes, landmarks, scores)` -> list[N] of list[{'bbox', 'landmarks', 'score'}]: row VIEWS into the
-arrays and numpy float32 scalars, exactly what the comprehension below yields (retinaface/wrapper.py:228-236).  The C
-module `_pyresults` (csrc/pyresults.c, built by terran_amd.build) does the same ~1.5x faster with the GIL held for that
-much less; without it the comprehension runs.  Host glue only: no arithmetic.
+arrays and numpy float32 scalars, exactly what `detections_py` below yields (retinaface/wrapper.py:228-236).
+
+The per-image lists are `LazyFaces`: a `list` subclass that creates its dicts the first time anything looks at them.  A
+detector call on a video batch returns thousands of detections (~11 000 per 32 1080p frames of noise through random
+weights); one dict + two array views + one numpy scalar each is ~150 ns through the C API (`_pyresults`, csrc/pyresults.c)
+and ~350 ns as a comprehension -- 0.7 - 2 ms per call with the GIL held, as long as the network itself takes on the device
+-- and most callers read a few faces per image (the pipeline's `pick_faces` reads the top F).  Until then a LazyFaces
+holds three array slices.  `len()` needs no dicts; indexing, slicing, iteration, comparison, mutation, pickling, `repr`
+and anything that goes through the sequence protocol (`list(x)`, `sorted`, `json.dumps`, `numpy.array`) fill the list first
+and then behave as the plain list they are.  TERRAN_AMD_EAGER_RESULTS=1 (or `eager(x)`) builds plain lists at once.
+Host glue only: no arithmetic.
 """
+import os
+
 try:
     from . import _pyresults
 except ImportError:                                   # not built (gcc / Python headers missing): same objects, slower
@@ -21,7 +31,73 @@ def detections_py(counts, boxes, landmarks, scores):
     return out
 
 
-def detections(counts, boxes, landmarks, scores):
+def detections_eager(counts, boxes, landmarks, scores):
     if _pyresults is not None:
         return _pyresults.detections(counts, boxes, landmarks, scores)
     return detections_py(counts, boxes, landmarks, scores)
+
+
+class LazyFaces(list):
+    """One image's detections.  Empty storage + the three result slices until first use (see the module text)."""
+    __slots__ = ('_src',)
+
+    def __init__(self, boxes, landmarks, scores):
+        list.__init__(self)
+        self._src = (boxes, landmarks, scores)
+
+    def _fill(self):
+        src = self._src
+        if src is not None:
+            self._src = None
+            b, l, s = src
+            if len(s):
+                import numpy as np
+                list.extend(self, detections_eager(np.array([len(s)], np.int32), b, l, s)[0])
+        return self
+
+    def __len__(self):
+        src = self._src
+        return len(src[2]) if src is not None else list.__len__(self)
+
+    def __reduce_ex__(self, protocol):                  # pickles / copies as the plain list it stands for
+        return (list, (list(self._fill()),))
+
+    def __repr__(self):
+        return list.__repr__(self._fill())
+
+    __hash__ = None
+
+
+def _filled(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
+        # list's own C code reads another list's items directly (concatenation, comparison): fill those as well
+        a = tuple(x._fill() if isinstance(x, LazyFaces) else x for x in a)
+        return base(self._fill(), *a, **k)
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _name in ('__getitem__', '__setitem__', '__delitem__', '__iter__', '__reversed__', '__contains__', '__eq__', '__ne__',
+              '__lt__', '__le__', '__gt__', '__ge__', '__add__', '__iadd__', '__mul__', '__rmul__', '__imul__', 'append',
+              'extend', 'insert', 'pop', 'remove', 'clear', 'index', 'count', 'sort', 'reverse', 'copy'):
+    setattr(LazyFaces, _name, _filled(_name))
+del _name
+
+
+def eager(dets):
+    """Plain lists of dicts out of whatever `detections` returned."""
+    return [list(d) for d in dets]
+
+
+def detections(counts, boxes, landmarks, scores):
+    if os.environ.get('TERRAN_AMD_EAGER_RESULTS'):
+        return detections_eager(counts, boxes, landmarks, scores)
+    out, o = [], 0
+    for c in (counts.tolist() if hasattr(counts, 'tolist') else counts):
+        c = int(c)
+        out.append(LazyFaces(boxes[o:o + c], landmarks[o:o + c], scores[o:o + c]))
+        o += c
+    return out

@@ -351,9 +351,9 @@ def test_c_result_builder_yields_the_comprehensions_objects():
         assert b[4, 0] == 77
     if results._pyresults is not None:
         with pytest.raises(ValueError):
-            results.detections(counts.astype(np.int64), boxes, lmks, scores)
+            results.detections_eager(counts.astype(np.int64), boxes, lmks, scores)
         with pytest.raises(ValueError):
-            results.detections(np.array([T + 3], np.int32), boxes, lmks, scores)
+            results.detections_eager(np.array([T + 3], np.int32), boxes, lmks, scores)
 
 
 def test_detector_lanes_are_closed_branches(monkeypatch):
@@ -558,3 +558,57 @@ def test_power_sampler_reads_hwmon_files_and_is_a_noop_without_them(tmp_path):
     summ = s.summary(skip_seconds=0.02)
     assert summ['power_w_mean'] == 1300.0 and summ['cap_w'] == 1400.0 and summ['sclk_mhz_min'] == 1900.0
     assert summ['samples'] < len(rows)
+
+
+def test_lazy_faces_behave_as_the_lists_they_stand_for():
+    """results.detections returns per-image `LazyFaces` (a list subclass that creates its dicts on first use): every way of
+    looking at one must give what the eager list of dicts gives."""
+    import copy
+    import json
+    import pickle
+    from terran_amd import results
+    rng = np.random.default_rng(0)
+    counts = np.array([3, 0, 5, 1], np.int32)
+    T = int(counts.sum())
+    boxes, lms, scores = (rng.normal(size=(T, 4)).astype(np.float32), rng.normal(size=(T, 5, 2)).astype(np.float32),
+                          rng.uniform(size=T).astype(np.float32))
+    want = results.detections_py(counts, boxes, lms, scores)
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert set(x) == {'bbox', 'landmarks', 'score'} and x['score'] == y['score'] and isinstance(x['score'], np.float32)
+            assert np.array_equal(x['bbox'], y['bbox']) and np.array_equal(x['landmarks'], y['landmarks'])
+            assert x['landmarks'].shape == (5, 2)
+
+    def fresh():
+        return results.detections(counts, boxes, lms, scores)
+    got = fresh()
+    assert isinstance(got, list) and all(isinstance(g, list) for g in got)
+    assert [len(g) for g in got] == counts.tolist() and [bool(g) for g in got] == [True, False, True, True]     # no dict built yet
+    assert all(g._src is not None for g in got)
+    for g, w in zip(got, want):
+        same(g, w)                                                     # iteration
+        assert all(d['bbox'].base is not None for d in g)               # views into the packed arrays, not copies
+    for mk in (lambda g: g[:2], lambda g: list(g), lambda g: sorted(g, key=lambda d: d['score']), lambda g: g + [],
+               lambda g: [] + list(g), lambda g: g.copy(), lambda g: copy.copy(g), lambda g: copy.deepcopy(g),
+               lambda g: pickle.loads(pickle.dumps(g)), lambda g: [d for d in reversed(g)][::-1], lambda g: g * 1):
+        for g, w in zip(fresh(), want):
+            ref = mk(w)
+            same(mk(g), ref)
+    g = fresh()[2]
+    assert g[0]['score'] == want[2][0]['score'] and g[-1]['score'] == want[2][-1]['score']
+    a, b = fresh()[0], fresh()[0]
+    assert len(a + b) == 6 and len(b) == 3                             # concatenation of two unfilled lists
+    a += fresh()[2]
+    assert len(a) == 8
+    g = fresh()[0]
+    g.append({'bbox': None})
+    assert len(g) == 4 and g.pop()['bbox'] is None and len(g) == 3
+    g.sort(key=lambda d: -d['score'])
+    assert [d['score'] for d in g] == sorted((d['score'] for d in want[0]), reverse=True)
+    assert repr(fresh()[3]) == repr(want[3]) and fresh()[1] == [] and not (fresh()[1] != [])
+    assert json.dumps([[float(d['score']) for d in g] for g in fresh()]) == json.dumps([[float(d['score']) for d in w] for w in want])
+    assert results.eager(fresh())[0][1]['score'] == want[0][1]['score'] and type(results.eager(fresh())[0]) is list
+    lazy_empty = results.detections(np.zeros(2, np.int32), boxes[:0], lms[:0], scores[:0])
+    assert lazy_empty == [[], []] and [len(x) for x in lazy_empty] == [0, 0]
