@@ -134,6 +134,32 @@ def dominant_kernel(precision, instances):
             'source': 'driver-run: HIP events around every launch of this instance in one serial step of this very process'}
 
 
+def roofline_object(precision, klass, step_seconds):
+    allc = dict(conv_roofline(precision, klass['conv_igemm']),
+                mfma_issue_frac_by_instance=issued_mfma_frac(precision, klass.get('instances')),
+                pipelined_achieved=round(klass['conv_igemm']['work'] / step_seconds / 1e12, 2),
+                pipelined_frac=round(klass['conv_igemm']['work'] / step_seconds / 1e12 / PEAKS[precision][0], 4))
+    dom = dominant_kernel(precision, klass.get('instances'))
+    if dom is None:                                    # no per-instance times (should not happen): the aggregate stands in
+        return dict(allc, all_conv_kernels=None)
+    r = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': 'TFLOP/s', 'frac': dom['frac'],
+         'traffic': None, 'mfma_issue_frac': dom['mfma_issue_frac'], 'launches_per_step': dom['launches_per_step'],
+         'avg_launch_ms': dom['avg_launch_ms'], 'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
+         'share_of_conv_time': dom['share_of_conv_time'], 'source': dom['source']}
+    pmc = os.path.join(REPO, 'profiles', 'pmc_conv_%s.json' % precision)
+    if os.path.exists(pmc):
+        inst = json.load(open(pmc)).get('per_instance', {}).get(dom['kernel'])
+        if inst:
+            r['traffic'] = inst['hbm_bytes_per_launch']
+            r['traffic_source'] = ('builder-run: profiles/pmc_conv_%s.json per_instance (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes: '
+                                   'HBM-side bytes per launch of this instance)' % precision)
+    for k_ in ('pmc_dominant_layers',):
+        if k_ in allc:
+            r[k_] = allc.pop(k_)
+    r['all_conv_kernels'] = allc
+    return r
+
+
 def conv_roofline(precision, conv):
     """`conv` = {'ms','launches','work'} of the implicit-GEMM kernels from HIP events on their launch streams."""
     achieved = conv['work'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
@@ -722,7 +748,7 @@ def run(args):
                 others[prec] = {'value': fps(r2['elapsed'], r2['steps']), 'steps': r2['steps'],
                                 'timed_region_s': round(r2['elapsed'], 3),
                                 'ms_per_step': round(r2['elapsed'] / r2['steps'] * 1e3, 3),
-                                'roofline': conv_roofline(prec, r2['klass']['conv_igemm']), 'power': r2.get('power'), '_out': r2['out']}
+                                'roofline': roofline_object(prec, r2['klass'], r2['elapsed'] / r2['steps']), 'power': r2.get('power'), '_out': r2['out']}
         legs['decoder_pose_weights']['_out'] = legs['decoder_pose_weights']['out']
         for prec, o in list(others.items()) + [(primary, legs['decoder_pose_weights'])]:
             dr = drift(o)
@@ -844,12 +870,11 @@ def run(args):
                                    'batches at once (>= %d crops or %.0f ms; %.0f crops per launch measured)'
                                    % (args.embed_min_crops, args.embed_max_wait * 1e3, head.get('crops_per_embed_launch', 0))),
             },
-            'roofline': dict(conv_roofline(primary, klass['conv_igemm']), dominant=dominant_kernel(primary, klass.get('instances')),
-                             mfma_issue_frac_by_instance=issued_mfma_frac(primary, klass.get('instances')),
-                             # the same algorithmic FLOPs over the PIPELINED step (what `value` is made of): above the serial
-                             # figure because concurrent streams fill the CUs one kernel's tail and launch gaps leave idle
-                             pipelined_achieved=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12, 2),
-                             pipelined_frac=round(klass['conv_igemm']['work'] / (elapsed / steps_timed) / 1e12 / PEAKS[primary][0], 4)),
+            # `roofline` = the DOMINANT kernel instance (most HIP-event time in one serial step of this process): algorithmic FLOPs per
+            # launch over its average launch duration.  `roofline.all_conv_kernels` = every implicit-GEMM launch of the step together
+            # (serial, and over the pipelined step `value` is made of -- above the serial figure because concurrent streams fill the
+            # CUs one kernel's tail and launch gaps leave idle).
+            'roofline': roofline_object(primary, klass, elapsed / steps_timed),
             'stage_ms_per_step': {k: v['ms'] for k, v in klass.items() if k != 'instances'},
             # algorithmic bytes / kernel time of the HBM-bound kernel classes (peak 8000 GB/s); post-processing
             # mixes the pose-map stream with latency-bound selection / grouping kernels
@@ -891,13 +916,13 @@ def run(args):
         # rank 0's GPU over the region `value` comes from, driver-run: amdgpu hwmon power1_* / freq1_input every 50 ms.  In
         # f16x3 the chip sits at its package power cap with the shader clock ~20 % under the 2.4 GHz the peak is quoted at
         # (DESIGN.md section 4); null when the box exposes no sensors
-        if head.get('power') and head['power'].get('sclk_mhz_mean'):
+        if head.get('power') and head['power'].get('sclk_mhz_mean') and result['roofline'].get('all_conv_kernels'):
             # the peak in `roofline.peak` is quoted at 2400 MHz; under its power cap the chip holds less: the same pipelined
             # figure against the peak AT THE CLOCK IT RAN AT (informative; `frac` stays against the nominal peak)
             held = head['power']['sclk_mhz_mean']
-            result['roofline']['held_clock_mhz'] = held
-            result['roofline']['pipelined_frac_at_held_clock'] = round(
-                result['roofline']['pipelined_achieved'] / (PEAKS[primary][0] * held / 2400.0), 4)
+            allc = result['roofline']['all_conv_kernels']
+            allc['held_clock_mhz'] = held
+            allc['pipelined_frac_at_held_clock'] = round(allc['pipelined_achieved'] / (PEAKS[primary][0] * held / 2400.0), 4)
         result['power'] = dict(head['power'], what='socket power (W) / shader clock (MHz) / hottest sensor (C) of rank 0\'s GPU over the '
                                'timed region, sysfs hwmon of its PCI function') if head.get('power') else None
         if 'ingest' in head:

@@ -68,6 +68,18 @@ def pmc_total(db_path, counter):
     return float(v), float(ns), n
 
 
+def pmc_per_instance(db_path, counter):
+    """{kernel instance: (sum of counter values, dispatches)} of the dense-conv kernels of one --pmc pass."""
+    cur = sqlite3.connect(db_path).cursor()
+    out = {}
+    for like in CONV_LIKE:
+        for name, v in cur.execute('select kernel_name, value from counters_collection where counter_name=? and kernel_name like ?', (counter, like)):
+            e = out.setdefault(_norm(name), [0.0, 0])
+            e[0] += v
+            e[1] += 1
+    return out
+
+
 def main(collect, prefix, steps=3):
     for P in ('f16x2', 'f16', 'f16x3', 'f32'):
         if not os.path.isdir(os.path.join(collect, 'kt_' + P)):
@@ -100,6 +112,12 @@ def main(collect, prefix, steps=3):
             busy, ns2, _ = pm['SQ_VALU_MFMA_BUSY_CYCLES']
             res.update({'effective_clock_ghz': cyc / 8.0 / ns, 'conv_kernel_ms_per_step': ns / 1e6 / steps,
                         'mfma_busy_frac_of_simd_cycles': (busy * (ns / ns2)) / (cyc / 8.0 * 1024.0)})
+        # the same two traffic counters per kernel INSTANCE (bench.py: `roofline.traffic` of the dominant instance)
+        dbf, dbw = find_db(os.path.join(collect, 'pmc_FETCH_SIZE_' + P)), find_db(os.path.join(collect, 'pmc_WRITE_SIZE_' + P))
+        if dbf and dbw:
+            pf, pw = pmc_per_instance(dbf, 'FETCH_SIZE'), pmc_per_instance(dbw, 'WRITE_SIZE')
+            res['per_instance'] = {k: {'launches': pf[k][1], 'hbm_bytes_per_launch': round((2.0 * pf[k][0] + pw.get(k, [0.0, 0])[0]) * 1024 / max(pf[k][1], 1))}
+                                   for k in sorted(pf)}
         res.update(out)
         json.dump(res, open('%s_pmc_conv_%s.json' % (prefix, P), 'w'), indent=1)
         print(P, json.dumps(res))

@@ -22,8 +22,8 @@ t1 = P.tensor(cin, k // 2)
 P.conv(t0, t1, rng.normal(0, 0.3, (cin, 3, 3, 3)).astype(np.float32), np.zeros(cin, np.float32), act=pack.ACT_RELU)
 t2 = P.tensor(cout, 1)
 P.conv(t1, t2, rng.normal(0, 0.05, (cout, cin, k, k)).astype(np.float32), np.zeros(cout, np.float32), act=pack.ACT_RELU)
-t3 = P.tensor(32, 0, f32=True)                                      # keeps t2 in the split format (lean epilogue)
-P.conv(t2, t3, rng.normal(0, 0.05, (32, cout, 3, 3)).astype(np.float32), np.zeros(32, np.float32))
+t3 = P.tensor(64, 0, f32=True)                                      # keeps t2 in the split format (lean epilogue)
+P.conv(t2, t3, rng.normal(0, 0.05, (64, cout, 3, 3)).astype(np.float32), np.zeros(64, np.float32))
 P.outputs = [t3]
 m = lib.Model(ctx, P)
 fr = ctx.upload(synth.frames(1, n, h, w))
