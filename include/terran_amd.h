@@ -219,6 +219,8 @@ int ta_bicubic_x8(ta_ctx* ctx, const float* maps, int n, int c, int h, int w, fl
                                 * pre-split half-float tensors; the K-split and the fused pool stay with the streaming kernels)  */
 #define TA_CONV_WIN_2x4 9      /* ... 128 x 256                                                       */
 #define TA_CONV_WIN_1x4 10     /* ... 64 cout x 256 px                                                */
+#define TA_CONV_SPLIT_1x4_W2 11 /* producer/consumer waves, 64 x 256, 2-stage ring: TWO workgroups per CU (short-K layers)  */
+#define TA_CONV_SPLIT_2x2_W2 12 /* ... 128 x 128                                                      */
 int ta_debug_conv_variant(ta_ctx* ctx, int variant);
 /* f16x3 mode: after ta_model_forward_* (the debug taps; the task entry points do this themselves), wait for the stream
  * and report whether an epilogue met |x| > 65504: TA_OK or TA_E_RANGE.  Clears the condition. */

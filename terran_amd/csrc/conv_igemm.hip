@@ -1459,10 +1459,15 @@ __device__ __forceinline__ bool conv_drain_dispatch(const ta_conv_launch& p, con
 // the 64 x 128 kernel above).  One s_barrier per slab hands a landed slab to the consumers and a drained stage back
 // to the producers.  The consumer loop is software-pipelined at k-step (16) granularity with the barrier in the
 // middle, so both fragment reads of a slab hide under 12 MFMAs each and only two 8-fragment sets are live.
+// STAGES == 2 (4 consumer waves only): the "two tiles per CU" variant for SHORT-K layers.  A 2-stage ring of a 128 x 128 or 64 x 256 tile
+// is <= 80 KiB, so two workgroups share a CU: one's fixed cost (kernel entry, address set-up, first DMA latency, park, drain: 10 - 12 k
+// cycles against the 14 - 28 k of an 18 / 36-slab loop) runs under the other's K loop.  Four waves per SIMD leave 128 VGPRs per lane: the
+// consumer keeps ONE fragment set (reads of a k-step, then its MFMAs) -- the LDS latency that the three-stage kernel hides inside a wave
+// is hidden by the other workgroup's consumer on the same SIMD.  Same tiles, K order and MFMA order: same bits.
 template <int CM, int CN, int NP, int PREC, int STAGES>
-__global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_igemm_split(const ta_conv_launch p) {
+__global__ __launch_bounds__(64 * (CM * CN + NP), STAGES == 2 ? 4 : (CM * CN + NP) / 4) void conv_igemm_split(const ta_conv_launch p) {
   static_assert(NP == 4 || NP == 8, "4 or 8 producer waves");
-  static_assert(STAGES == 3, "the producer's issue order and waits are written for a 3-stage ring");
+  static_assert(STAGES == 3 || (STAGES == 2 && CM * CN == 4 && NP == 4), "3-stage ring, or the 2-stage two-workgroups-per-CU variant of the 8-wave tiles");
   static_assert(CM * CN == 4 || CM * CN == 8, "consumer grid: 1x4 (64 cout x 256 px), 2x2 (128 x 128) or 2x4 (128 x 256)");
   constexpr int NC = CM * CN;                    // consumer waves (the first NC waves of the workgroup)
   constexpr int BN = CM * 64, BM = CN * 64;
@@ -1557,7 +1562,21 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
     if ((p.probe & 4)) issue_b(0);                        // tools (TA_CONV_LATE_B): the round-2 order, all addresses first
     if (S > 1) issue_b(1);
     if (wave == NC) TA_STAMP(10);                    // producer: first slabs issued
-    int stage = 2;                                  // stage the next issued slab goes to
+    int stage = STAGES == 2 ? 0 : 2;                // stage the next issued slab goes to
+    if constexpr (STAGES == 2) {
+      // two stages: slabs 0 and 1 are in flight; slab s + 1 (s >= 1) goes out once B_s has handed back the stage of slab s - 1
+      for (int s = 0; s < S; ++s) {
+        if (s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - QA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // B_s
+        asm volatile("" ::: "memory");
+        if (s >= 1 && s + 1 < S) {
+          issue_a(s + 1, stage);
+          issue_b(stage);
+          stage ^= 1;
+        }
+      }
+    } else
     for (int s = 0; s < S; ++s) {
       // slab s must have landed; issue order was [A0 A1 B0 B1] then [A B] per slab, and vmcnt counts in issue order
       if ((p.probe & 3) && s > 0) {                        // tools only (timing ablation): fewer DMAs in flight
@@ -1681,6 +1700,21 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
   __builtin_amdgcn_s_barrier();                     // B_0: slab 0 visible
   asm volatile("" ::: "memory");
   if (wave == 0) TA_STAMP(2);                       // consumer: slab 0 landed
+  if constexpr (STAGES == 2) {
+    // one fragment set: the other workgroup's consumer on this SIMD covers the read latency
+    for (int s = 0; s < S; ++s) {
+      const float* st = lds + (s & 1) * STAGE;
+      load(F0, st, 0);
+      mma(F0);
+      load(F0, st, 1);
+      mma(F0);
+      if (s + 1 < S) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // B_{s+1}
+        asm volatile("" ::: "memory");
+      }
+    }
+  } else {
   load(F0, lds + stage * STAGE, 0);
   for (int s = 0; s + 1 < S; ++s) {                 // branch-free body; the last slab is peeled below
     const float* st = lds + stage * STAGE;
@@ -1702,6 +1736,7 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), (CM * CN + NP) / 4) void conv_
   stage = stage + 1 == STAGES ? 0 : stage + 1;
   mma(F0);
   mma(F1);
+  }
   if (wave == 0) TA_STAMP(3);                       // consumer: main loop done (last MFMAs issued)
   {
     __builtin_amdgcn_s_barrier();                   // E0: every consumer has its last fragments: the ring can be reused
@@ -2239,6 +2274,8 @@ static bool variant_eligible(int v, const ta_conv_launch& p) {
     case TA_CV_SPLIT_2x2_P8:
     case TA_CV_SPLIT_2x4: return deep && split_in && staged && p.coutp % 128 == 0;
     case TA_CV_SPLIT_1x4: return deep && split_in && staged && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0);
+    case TA_CV_SPLIT_2x2_W2: return deep && split_in && staged && p.coutp % 128 == 0 && p.k_split <= 1;
+    case TA_CV_SPLIT_1x4_W2: return deep && split_in && staged && p.coutp % 64 == 0 && (!p.group_cout || p.group_cout % 64 == 0) && p.k_split <= 1;
     case TA_CV_WIN_2x2:
     case TA_CV_WIN_2x4:
     case TA_CV_WIN_1x4: {
@@ -2279,7 +2316,14 @@ static int choose_variant_streamed(const ta_conv_launch& p) {
       }
       return TA_CV_SPLIT_2x2;
     }
-    if (variant_eligible(TA_CV_SPLIT_1x4, p)) return TA_CV_SPLIT_1x4;
+    if (variant_eligible(TA_CV_SPLIT_1x4, p)) {
+      // 64-channel layers with a short K (18 slabs: conv1_2 of the pose network, 544 us per step) and many tiles: two workgroups
+      // per CU on a 2-stage ring hide one tile's fixed cost under the other's loop (+6 ... 10 % on those shapes, tools/conv_bench.py)
+      static const bool no_w2 = getenv("TA_CONV_NO_W2") != nullptr;
+      if (!no_w2 && p.prec != PREC_F32 && p.n_slabs <= 18 && (p.M + 255) / 256 * (p.coutp / 64) >= 1024 && variant_eligible(TA_CV_SPLIT_1x4_W2, p))
+        return TA_CV_SPLIT_1x4_W2;
+      return TA_CV_SPLIT_1x4;
+    }
     if (variant_eligible(TA_CV_PIPE64, p)) return TA_CV_PIPE64;
   }
   return TA_CV_GENERIC;
@@ -2302,6 +2346,8 @@ static int launch_variant(ta_ctx* ctx, int v, const ta_conv_launch& p) {
     case TA_CV_SPLIT_2x2_P8: return launch_split<2, 2, 8, PREC, 3>(ctx, p);
     case TA_CV_SPLIT_2x4: return launch_split<2, 4, 4, PREC, 3>(ctx, p);
     case TA_CV_SPLIT_1x4: return launch_split<1, 4, 4, PREC, 3>(ctx, p);
+    case TA_CV_SPLIT_1x4_W2: return launch_split<1, 4, 4, PREC, 2>(ctx, p);
+    case TA_CV_SPLIT_2x2_W2: return launch_split<2, 2, 4, PREC, 2>(ctx, p);
     case TA_CV_WIN_2x2:
     case TA_CV_WIN_2x4:
     case TA_CV_WIN_1x4:
@@ -2335,14 +2381,14 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
       return ta_fail(ctx, TA_E_INVALID, "conv: forced kernel variant %d cannot run this layer (cin-uniform %d, slabs %d, coutp %d, "
                      "input format %d, groups %d)", v, p.uniform_k, p.n_slabs, p.coutp, p.in_fmt, p.group_cout ? 1 : 0);
   } else {
-    auto is_split_v = [](int x) { return x == TA_CV_SPLIT_2x2 || x == TA_CV_SPLIT_2x2_P8 || x == TA_CV_SPLIT_2x4 || x == TA_CV_SPLIT_1x4; };   // (the window kernels have no fused pool)
+    auto is_split_v = [](int x) { return x == TA_CV_SPLIT_2x2 || x == TA_CV_SPLIT_2x2_P8 || x == TA_CV_SPLIT_2x4 || x == TA_CV_SPLIT_1x4 || x == TA_CV_SPLIT_1x4_W2 || x == TA_CV_SPLIT_2x2_W2; };   // (the window kernels have no fused pool)
     const bool prefer = ctx->conv_force && variant_eligible(ctx->conv_force, p) && (!p.pool || is_split_v(ctx->conv_force));
     v = prefer ? ctx->conv_force : choose_variant(p);
     if (!variant_eligible(v, p)) return ta_fail(ctx, TA_E_INVALID, "conv: pre-split input reached a kernel that cannot read it");
   }
   const bool is_win = v == TA_CV_WIN_2x2 || v == TA_CV_WIN_2x4 || v == TA_CV_WIN_1x4;
-  const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4;
-  if (!is_split) p.k_split = 1;
+  const bool is_split = v == TA_CV_SPLIT_2x2 || v == TA_CV_SPLIT_2x2_P8 || v == TA_CV_SPLIT_2x4 || v == TA_CV_SPLIT_1x4 || v == TA_CV_SPLIT_1x4_W2 || v == TA_CV_SPLIT_2x2_W2;
+  if (!is_split || v == TA_CV_SPLIT_1x4_W2 || v == TA_CV_SPLIT_2x2_W2) p.k_split = 1;
   (void)is_win;
   if (p.pool) {                                      // only the split-role kernel's LDS-staged epilogue knows 2x2 windows
     if (!is_split || p.res || p.out2 || (p.out_ch & 7) || (p.M & 3) || (p.act != TA_ACT_RELU && p.act != TA_ACT_NONE))

@@ -186,6 +186,8 @@ enum {
   TA_CV_WIN_2x2 = 8,      // conv_igemm_win<2,2>: 128 x 128, the pixel operand of a channel block resident in LDS (stride-1 convs, >= 4 taps)
   TA_CV_WIN_2x4 = 9,      // conv_igemm_win<2,4>: 128 x 256
   TA_CV_WIN_1x4 = 10,     // conv_igemm_win<1,4>: 64 cout x 256 px
+  TA_CV_SPLIT_1x4_W2 = 11,  // conv_igemm_split<1,4,4,.,2>: 64 x 256 on a 2-stage ring, TWO workgroups per CU (short-K layers)
+  TA_CV_SPLIT_2x2_W2 = 12,  // conv_igemm_split<2,2,4,.,2>: 128 x 128, likewise
   TA_CV_COUNT = 16
 };
 

@@ -84,7 +84,7 @@ SIGNATURES = {
 
 # conv kernel variants (include/terran_amd.h TA_CONV_*)
 CONV_VARIANTS = {'auto': 0, 'generic': 1, 'pipe64': 2, 'pipe128': 3, 'split_2x2': 4, 'split_2x2_p8': 5, 'split_2x4': 6,
-                 'split_1x4': 7, 'win_2x2': 8, 'win_2x4': 9, 'win_1x4': 10}
+                 'split_1x4': 7, 'win_2x2': 8, 'win_2x4': 9, 'win_1x4': 10, 'split_1x4_w2': 11, 'split_2x2_w2': 12}
 
 _lib = None
 

@@ -63,7 +63,7 @@ def main():
     bad = 0
     for i in range(n):
         case = draw(rng)
-        for prec in ('f32', 'f16x3', 'bf16x3', 'f16'):
+        for prec in ('f32', 'f16x3', 'bf16x3', 'f16', 'f16x2'):
             if prec == 'f16' and case.get('groups', 1) > 1:      # the single-half mode has no grouped convs
                 continue
             try:
@@ -72,7 +72,7 @@ def main():
                 bad += 1
                 print('FAIL', prec, case)
                 print('   ', ''.join(traceback.format_exception_only(type(e), e)).strip()[:600])
-    print('%d cases x 4 precisions, %d failures' % (n, bad))
+    print('%d cases x 5 precisions, %d failures' % (n, bad))
     return 1 if bad else 0
 
 

@@ -81,6 +81,10 @@ CASES = [
     ('small_pool', 'split_1x4', False), ('small_pool', 'auto', False), ('small_pool_128', 'split_2x2', False), ('small_pool_128', 'split_2x4', False),
     ('small_res_out2', 'split_2x2', False), ('small_res_out2', 'split_2x4', False), ('small_prelu_256', 'split_2x2', False),
     ('small_prelu_256', 'split_2x4', False), ('small_plain_1x1', 'split_2x2', False),
+    # the 2-stage, two-workgroups-per-CU variants (short-K layers): same tiles, K order and epilogues
+    ('vgg3x3_64_c5', 'split_1x4_w2', False), ('vgg3x3_64_pool_c5', 'split_1x4_w2', False), ('small_pool', 'split_1x4_w2', False),
+    ('pose7x7_grouped_c5', 'split_1x4_w2', False), ('arc3x3_256_c3', 'split_2x2_w2', False), ('arc3x3_s2_res_out2', 'split_2x2_w2', False),
+    ('vgg3x3_128_pool_c5', 'split_2x2_w2', False), ('small_res_out2', 'split_2x2_w2', False), ('small_plain_1x1', 'split_2x2_w2', False),
 ]
 
 _ref_cache = {}

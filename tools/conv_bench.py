@@ -22,6 +22,7 @@ SHAPES = [
     ('arc  3x3 256->256 @256x14x14', 256, 14, 14, 256, 256, 3, 1),
     ('arc  3x3 128->128 @64x28x28', 64, 28, 28, 128, 128, 3, 1),
     ('arc  3x3 64->64 @64x56x56', 64, 56, 56, 64, 64, 3, 1),
+    ('vgg  3x3 64->64 @32x184x327', 32, 184, 327, 64, 64, 3, 1),
     ('pose 3x3 256->256 @32x46x81', 32, 46, 81, 256, 256, 3, 1),
     ('pose 3x3 128->128 @32x92x163', 32, 92, 163, 128, 128, 3, 1),
 ]
