@@ -2320,7 +2320,9 @@ static int choose_variant_streamed(const ta_conv_launch& p) {
       // 64-channel layers with a short K (18 slabs: conv1_2 of the pose network, 544 us per step) and many tiles: two workgroups
       // per CU on a 2-stage ring hide one tile's fixed cost under the other's loop (+6 ... 10 % on those shapes, tools/conv_bench.py)
       static const bool no_w2 = getenv("TA_CONV_NO_W2") != nullptr;
-      if (!no_w2 && p.prec != PREC_F32 && p.n_slabs <= 18 && (p.M + 255) / 256 * (p.coutp / 64) >= 1024 && variant_eligible(TA_CV_SPLIT_1x4_W2, p))
+      static const int w2_tiles = getenv("TA_CONV_W2_TILES") ? atoi(getenv("TA_CONV_W2_TILES")) : 1024;     // tools: the threshold
+      static const int w2_slabs = getenv("TA_CONV_W2_SLABS") ? atoi(getenv("TA_CONV_W2_SLABS")) : 18;
+      if (!no_w2 && p.prec != PREC_F32 && p.n_slabs <= w2_slabs && (p.M + 255) / 256 * (p.coutp / 64) >= w2_tiles && variant_eligible(TA_CV_SPLIT_1x4_W2, p))
         return TA_CV_SPLIT_1x4_W2;
       return TA_CV_SPLIT_1x4;
     }

@@ -22,6 +22,10 @@ SHAPES = [
     ('arc  3x3 256->256 @256x14x14', 256, 14, 14, 256, 256, 3, 1),
     ('arc  3x3 128->128 @64x28x28', 64, 28, 28, 128, 128, 3, 1),
     ('arc  3x3 64->64 @64x56x56', 64, 56, 56, 64, 64, 3, 1),
+    # the transform-domain products of Winograd F(2x2, 3x3) as 1x1 convs of the same dimensions (16 positions x tiles = 'pixels', K = cin):
+    # what the MFMA part of such a layer would cost on the kernels that exist, before any transform
+    ('wino-domain of arc 256->256 @64x14x14: 1x1 @64x28x28', 64, 28, 28, 256, 256, 1, 1),
+    ('wino-domain of pose 256->256 @32x46x81: 1x1 @32x122x124', 32, 122, 124, 256, 256, 1, 1),
     ('vgg  3x3 64->64 @32x184x327', 32, 184, 327, 64, 64, 3, 1),
     ('pose 3x3 256->256 @32x46x81', 32, 46, 81, 256, 256, 3, 1),
     ('pose 3x3 128->128 @32x92x163', 32, 92, 163, 128, 128, 3, 1),
@@ -59,7 +63,7 @@ def bench(ctx, name, n, h, w, cin, cout, k, groups, precision, reps=20):
     flops_layer = 2.0 * n * h * w * cout * (cout // groups) * k * k
     per_layer_ms = ms / reps / (layers + 1) * (layers + 1)      # total per forward
     tf = (layers * flops_layer) / (per_layer_ms * 1e-3) / 1e12
-    print('%-42s %-7s %7.3f ms/forward(%d layers)  ~%6.1f TF  %s' % (name, precision, per_layer_ms, layers, tf,
+    print('%-58s %-7s %7.3f ms/forward(%d layers)  ~%6.1f TF  %s' % (name, precision, per_layer_ms, layers, tf,
                                                                     ctx.conv_counts(reset=True)))
     m.free()
     fr.free()
