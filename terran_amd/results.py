@@ -14,6 +14,11 @@ and then behave as the plain list they are.  TERRAN_AMD_EAGER_RESULTS=1 (or `eag
 Host glue only: no arithmetic.
 """
 import os
+import threading
+
+import numpy as _np
+
+_fill_lock = threading.Lock()
 
 try:
     from . import _pyresults
@@ -46,13 +51,14 @@ class LazyFaces(list):
         self._src = (boxes, landmarks, scores)
 
     def _fill(self):
-        src = self._src
-        if src is not None:
-            self._src = None
-            b, l, s = src
-            if len(s):
-                import numpy as np
-                list.extend(self, detections_eager(np.array([len(s)], np.int32), b, l, s)[0])
+        if self._src is not None:
+            with _fill_lock:                            # two threads looking at one unfilled list: one of them builds it
+                src = self._src
+                if src is not None:
+                    b, l, s = src
+                    if len(s):
+                        list.extend(self, detections_eager(_np.array([len(s)], _np.int32), b, l, s)[0])
+                    self._src = None                    # only now: a reader that sees None sees the items
         return self
 
     def __len__(self):
