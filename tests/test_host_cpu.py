@@ -612,3 +612,75 @@ def test_lazy_faces_behave_as_the_lists_they_stand_for():
     assert results.eager(fresh())[0][1]['score'] == want[0][1]['score'] and type(results.eager(fresh())[0]) is list
     lazy_empty = results.detections(np.zeros(2, np.int32), boxes[:0], lms[:0], scores[:0])
     assert lazy_empty == [[], []] and [len(x) for x in lazy_empty] == [0, 0]
+
+
+def test_embed_worker_launch_rule(monkeypatch):
+    """pipeline._Embedder without a GPU (contexts and the model stubbed): it launches on >= min_crops, it does NOT sit out
+    `max_wait` when no shard of its device is between upload and detect (a consumer that feeds one batch at a time), it DOES wait
+    for a shard that was announced, and a worker that dies lets go of the frames still queued for it."""
+    import queue
+    import time
+    from terran_amd import affinity, pipeline, runtime
+
+    class Ctx:
+        def close(self):
+            pass
+    monkeypatch.setattr(runtime, 'new_context', lambda d=None: Ctx())
+    monkeypatch.setattr(affinity, 'bind', lambda d: {})
+    launches = []
+
+    class Model:
+        def call_multi(self, items):
+            launches.append((time.perf_counter(), sum(sum(len(f) for f in faces) for _, faces in items)))
+            if any(fr == 'boom' for fr, _ in items):
+                raise RuntimeError('boom')
+            return [[np.zeros((len(f), 512)) for f in faces] for _, faces in items]
+
+        def free(self):
+            pass
+
+    class Rec:
+        model = Model()
+
+    class Refs:
+        def __init__(self):
+            self.released = 0
+
+        def release(self):
+            self.released += 1
+    out, errs, live = queue.Queue(), [], {1}
+    emb = pipeline._Embedder(0, lambda dev, ctx: Rec(), out, errs.append, live, min_crops=8, max_crops=16, max_wait=0.5)
+
+    def shard(key, n_faces, frames='fr'):
+        return (1, key, frames, [[{}] * n_faces], Refs(), n_faces)
+    # (1) one small shard, nothing upstream: launched at once, not after max_wait
+    t0 = time.perf_counter()
+    emb.announce()
+    emb.deliver(shard('a', 2))
+    assert out.get(timeout=5)[1] == 'a' and time.perf_counter() - t0 < 0.25 and launches[-1][1] == 2
+    # (2) a second shard is announced before the first arrives: the worker waits for it and embeds both in ONE launch
+    emb.announce()
+    emb.announce()
+    emb.deliver(shard('b', 3))
+    time.sleep(0.1)
+    assert out.empty() and len(launches) == 1                    # still waiting: upstream > 0, min_crops not reached
+    emb.deliver(shard('c', 6))
+    got = {out.get(timeout=5)[1], out.get(timeout=5)[1]}
+    assert got == {'b', 'c'} and len(launches) == 2 and launches[-1][1] == 9
+    # (3) a shard that would overflow max_crops is carried to the next launch
+    for k, n in (('d', 7), ('e', 12)):
+        emb.announce()
+        emb.deliver(shard(k, n))
+    assert {out.get(timeout=5)[1], out.get(timeout=5)[1]} == {'d', 'e'} and [l[1] for l in launches[-2:]] == [7, 12]
+    # (4) the worker dies: what is still queued is released, the failure is reported
+    emb.announce()
+    emb.announce()
+    bad, waiting = shard('f', 9, frames='boom'), shard('g', 1)
+    emb.q.put(bad)
+    emb.q.put(waiting)
+    deadline = time.perf_counter() + 5
+    while not errs and time.perf_counter() < deadline:
+        time.sleep(0.01)
+    assert errs and bad[4].released == 1
+    emb.thread.join(timeout=5)
+    assert waiting[4].released == 1
