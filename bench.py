@@ -17,21 +17,25 @@ measured as well and reported under `other_faces_per_frame`).  Per GPU the host 
 three threads / HIP streams (detect -> queue -> embed, pose); all K steps complete inside the timed region.  Frames
 shard embarrassingly: every rank owns its own batches, there is no data-path collective ("scaling": "weak").
 
-The ONE JSON line rank 0 prints carries, next to the headline (`value`: f16x3 mode, the library default -- split-half
-operands, 22 bits, float32-grade results: tests/test_gpu_decisions_vs_oracle.py -- frames resident in HBM):
+stdout carries ONE JSON line of <= 8 KB (`compact_line`): the headline (`value`: f16x3 mode, the library default --
+split-half operands, 22 bits, three f16 MFMAs per product, float32-grade results: tests/test_gpu_decisions_vs_oracle.py --
+frames resident in HBM, ONE resident batch re-used by every step: `config.resident_batch_reused`), the dominant kernel
+instance's `roofline`, `cpu_baseline`, and beside them
   value_f32 / roofline_f32      the same workload with every conv on the exact-f32 MFMA (the like-for-like arithmetic)
-  value_ingest                  = ingest.value: the figure comparable with the reference's `.call`, whose first act is the
-                                host -> device copy of the batch (retinaface/wrapper.py:144)
+  value_f16x2                   the opt-in tolerance mode: the embedder alone on two of the three products (<= 5e-4 guarded at load)
+  value_ingest                  the same workload fed from HOST memory: a raw rgb24 byte stream read into pinned buffers and
+                                uploaded by video.RawVideoReader threads (upload overlapped with compute), every step a fresh
+                                batch, results gathered in order on rank 0 WHILE the region runs (a gather thread per rank) --
+                                the figure comparable with the reference's `.call`, whose first act is the host -> device
+                                copy of the batch (retinaface/wrapper.py:144)
   value_k_steps                 the exact K = --steps region (`value` itself is quoted from a region of >= 2.5 s: a 0.25 s
                                 region reads ~8 % above what the loop sustains -- the chip clocks to its power budget)
-  value_f16_embedder            the opt-in tolerance mode: the embedder alone on one f16 MFMA per product (3.6e-4 of a 1e-3 bar)
-  ingest                        the same workload fed from HOST memory: a raw rgb24 byte stream read into pinned buffers
-                                and uploaded by video.RawVideoReader threads (upload overlapped with compute), results
-                                gathered in order on rank 0 every step -- the SURVEY.md 8(e) pipeline with its scatter
-                                (H2D) and gather inside the timed region
   per_model                     BASELINE configs C2 (RetinaFace 32x640x640), C3 (ArcFace 256 crops), C4 (OpenPose
-                                16x368x656), each with its own roofline (N = 1 only)
-  roofline / cpu_baseline       see README / DESIGN.md section 5
+                                16x368x656): images/s and roofline fraction each (N = 1 only)
+Everything else this run measured (every leg's full roofline object, power, per-rank host figures, per-model rows, the prose)
+goes to `gpurun_out/bench_detail.json` (`--detail PATH`) and to stderr; `--full` adds the legs of earlier rounds (bf16x3 / f16 /
+bf16 precisions, 1 and 4 faces per frame, pose weights without structured zeros); `--full-line` prints the detail object on
+stdout instead of the compact line (tools/*.sh).
 `python bench.py --gpus N --single-process` (no torchrun) drives N devices from ONE process through
 terran_amd.pipeline.StreamPipeline (per device: lanes of upload / detect -> embed / pose threads) instead of one process
 per GPU; `--devices 0,0` puts two replicas on one card.
@@ -63,11 +67,19 @@ PEAKS = {
     'f16x2': (2500.0, 'v_mfma_f32_32x32x16_f16: x3 (split-half operands) in the detector and the pose network, x2 in the embedder ((w_hi + w_lo) * x_hi)', 3),
 }
 HBM_PEAK_GBPS = 8000.0
-# The mode `value` is measured in = the LIBRARY DEFAULT (runtime.resolve_precision): every network on the float32-grade split-half
+# The mode `value` is measured in = the LIBRARY DEFAULT (runtime.DEFAULT_PRECISION): every network on the float32-grade split-half
 # arithmetic (x = hi + lo, 22 significant bits, three f16 MFMAs per product; 0 decision flips vs the oracle, embeddings to 5e-7).
-# Beside it in the same line: `value_f16_embedder` (the opt-in tolerance mode: the embedder alone on one f16 MFMA per product,
-# embeddings 3.6e-4 against north_star's 1e-3 bar) and `value_f32` (every conv on the exact-f32 MFMA).
-HEADLINE = 'f16x2'
+# Beside it in the same line: `value_f16x2` (the opt-in tolerance mode: the embedder alone on two of the three products, guarded
+# at load time, arcface.calibrate_f16x2) and `value_f32` (every conv on the exact-f32 MFMA).
+HEADLINE = 'f16x3'
+SIDE_PRECISIONS = ('f32', 'f16x2')                                    # default side legs; --full: + bf16x3, f16, bf16
+# `dtype` of the compact line: <= 200 characters
+DTYPE_SHORT = {'f32': 'f32 (v_mfma_f32_32x32x2_f32)',
+               'f16x3': 'f16x3: operands x = hi + lo (two IEEE halfs, 22 bits), 3 f16 MFMAs per product, f32 accumulate; float32-grade results',
+               'bf16x3': 'bf16x3: operands x = hi + lo (two bf16, 16 bits), 3 bf16 MFMAs per product, f32 accumulate',
+               'bf16': 'bf16 (f32 accumulate); throughput mode outside the parity bar',
+               'f16x2': 'f16x3 for detector + pose; embedder on 2 of the 3 products ((w_hi + w_lo) * x_hi), guarded <= 5e-4 at load',
+               'f16': 'f16x3 for detector + pose; embedder on one f16 MFMA per product (tolerance mode)'}
 DTYPES = {'f32': 'f32',
           'f16x3': 'f16x3 (ArcFace / OpenPose operands x = hi + lo as two IEEE half floats = 22 significant bits, weight rows '
                    'scaled by a power of two per OUTPUT CHANNEL, stored activations by one per channel; 3 f16 MFMAs per product term (every product exact), f32 '
@@ -231,6 +243,12 @@ def main():
                     help='conv arithmetic mode of the headline number (default: $TERRAN_AMD_PRECISION or f16x3)')
     ap.add_argument('--single-mode', action='store_true',
                     help='headline measurement only (no f32 / faces-per-frame / sustained / ingest / per-model legs)')
+    ap.add_argument('--full', action='store_true',
+                    help='also the legs of earlier rounds: bf16x3 / f16 / bf16 precisions, 1 and 4 faces per frame, pose weights '
+                         'without structured zeros, the embedder modes beside each other at C3 (detail file only)')
+    ap.add_argument('--full-line', action='store_true', help='print the detail object on stdout instead of the compact line (tools)')
+    ap.add_argument('--detail', default=os.path.join(REPO, 'gpurun_out', 'bench_detail.json'),
+                    help='where rank 0 writes everything the run measured (the stdout line is the <= 8 KB summary of it)')
     ap.add_argument('--no-side-legs', action='store_true',
                     help='headline + ingest legs only (no other precisions / faces per frame / random-weights / per-model legs): multi-rank rehearsals')
     ap.add_argument('--inflight', type=int, default=4, help='lanes per GPU: batches in flight, each on its own upload / detect / embed / pose streams')
@@ -269,8 +287,94 @@ def main():
     finally:
         sys.stdout.flush()
     if result is not None:
-        os.write(real_stdout, (json.dumps(result) + '\n').encode())
+        detail = json.dumps(result)
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, 'w') as f:
+                f.write(detail + '\n')
+        except OSError as e:
+            print('bench: could not write %s: %s' % (args.detail, e), file=sys.stderr)
+        print(detail, file=sys.stderr)
+        sys.stderr.flush()
+        line = detail if (args.full_line or args.serial) else compact_line(result, os.path.relpath(args.detail, REPO))
+        os.write(real_stdout, (line + '\n').encode())
     os.close(real_stdout)
+
+
+LINE_LIMIT = 8192          # the driver keeps the last 8 KB of stdout: the line must fit (tests/test_host_cpu.py::test_bench_line_is_compact)
+ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step',
+                 'algorithmic_gflop_per_launch', 'mfma_issue_frac', 'share_of_conv_time')
+
+
+def _roof(r, keys=ROOFLINE_KEYS):
+    return {k: r[k] for k in keys if k in r} if isinstance(r, dict) else None
+
+
+def compact_line(result, detail_path=None):
+    """The ONE stdout line: the contract's keys, the dominant kernel's roofline, the CPU baseline and the side figures the
+    reader needs next to the headline -- no prose, <= LINE_LIMIT bytes.  `result` is what run() / run_single_process() return
+    (the detail object).  Optional blocks are dropped, least important first, should the line ever outgrow the limit."""
+    r = result
+    cfg = r.get('config', {})
+    host = (cfg.get('host_per_rank') or [{}])[0]
+    prec = cfg.get('precision')
+    line = {k: r.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'timed_region_s', 'timed_steps',
+                                  'higher_is_better', 'scaling', 'vs_baseline')}
+    line['dtype'] = DTYPE_SHORT.get(prec, str(r.get('dtype')))[:200]
+    line['data'] = r.get('data')
+    line['config'] = {k: v for k, v in (
+        ('workload', cfg.get('workload_short') or str(cfg.get('workload'))[:200]),
+        ('precision', prec),
+        ('frames_per_gpu_step', cfg.get('frames_per_gpu_step', cfg.get('frames_per_step'))),
+        ('faces_per_frame', cfg.get('faces_per_frame')),
+        ('resident_batch_reused', cfg.get('resident_batch_reused', True)),
+        ('batches_in_flight_per_gpu', cfg.get('batches_in_flight_per_gpu')),
+        ('detections_per_frame', cfg.get('detections_per_frame')),
+        ('humans_per_frame', cfg.get('humans_per_frame')),
+        ('host_cpu_s_per_step', host.get('cpu_s_per_step')),
+        ('host_threads', host.get('threads')),
+        ('sharding', 'frames over ranks, no collective')) if v is not None}
+    line['roofline'] = _roof(r.get('roofline'))
+    cb = r.get('cpu_baseline')
+    if isinstance(cb, dict):
+        line['cpu_baseline'] = {k: (v[:160] if isinstance(v, str) else v) for k, v in cb.items()
+                                if k in ('value', 'unit', 'cores', 'kind', 'sample', 'error')}
+    for k in ('value_k_steps', 'value_f32', 'value_f16x3', 'value_f16x2', 'value_ingest'):
+        if r.get(k) is not None:
+            line[k] = r[k]
+    if isinstance(r.get('roofline_f32'), dict):
+        line['roofline_f32'] = _roof(r['roofline_f32'], ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'launches_per_step'))
+    dd = r.get('decision_drift')
+    if isinstance(dd, dict):
+        line['decision_drift'] = {k: dd[k] for k in ('detections', 'detections_differ', 'people', 'people_differ', 'embedding_max_abs_diff') if k in dd}
+        line['decision_drift']['vs'] = 'f32 leg'
+    pw = r.get('power')
+    if isinstance(pw, dict):
+        line['power'] = {k: pw[k] for k in ('power_w_mean', 'cap_w', 'sclk_mhz_mean', 'energy_j_per_frame', 'throttle') if k in pw}
+    ing = r.get('ingest')
+    if isinstance(ing, dict):
+        line['ingest'] = {k: ing[k] for k in ('steps', 'ms_per_step', 'gather_tail_s', 'gather_messages', 'steps_gathered_on_rank0', 'error') if k in ing}
+    pm = r.get('per_model')
+    if isinstance(pm, dict):
+        rows = {}
+        for name, row in pm.items():
+            if isinstance(row, dict) and 'roofline' in row and '(' not in name:
+                rf = row['roofline']
+                rows[name] = {'images_per_s': row.get('images_per_s'), 'bound': rf.get('bound'), 'achieved': rf.get('achieved'),
+                              'unit': rf.get('unit'), 'frac': rf.get('frac')}
+        line['per_model'] = rows or {k: str(v)[:120] for k, v in pm.items()}
+    if r.get('c2_retinaface_640'):
+        line['c2_retinaface_640_images_per_s'] = r['c2_retinaface_640'].get('images_per_s')
+    if detail_path:
+        line['detail'] = detail_path
+    out = json.dumps(line)
+    for k in ('per_model', 'ingest', 'power', 'decision_drift', 'roofline_f32'):     # never expected: the line is ~3 KB
+        if len(out) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+        out = json.dumps(line)
+    assert len(out) < LINE_LIMIT, len(out)
+    return out
 
 
 def make_workload(args, rank):
@@ -586,7 +690,7 @@ def run(args):
             engine['resident'] = engine['sp'].scatter(work['frames'])            # resident in HBM before timing
         if args.warmup:
             run_steps(args.warmup if not streaming else max(args.warmup, 2 * L))      # every lane warms its plans
-        sampler = telemetry.PowerSampler(power_hw).start()          # this rank's GPU: socket power / shader clock (sysfs)
+        sampler = telemetry.PowerSampler(power_hw, bdf=placement.get('pci')).start()   # this rank's GPU: socket power / shader clock (sysfs), energy / throttlers (SMI)
         cpu0 = time.process_time()
         elapsed, out = timed(steps)
         res = {'elapsed_k': elapsed, 'steps_k': steps, 'elapsed': elapsed, 'steps': steps, 'out': out}
@@ -599,7 +703,7 @@ def run(args):
         if min_seconds > 0 and elapsed < min_seconds and not (args.serial or args.join_steps):
             k = int(np.ceil(min_seconds / (elapsed / steps)))
             sampler.stop()
-            sampler = telemetry.PowerSampler(power_hw).start()
+            sampler = telemetry.PowerSampler(power_hw, bdf=placement.get('pci')).start()
             cpu0 = time.process_time()
             e2, out = timed(k)
             res.update(elapsed=e2, steps=k, out=out)
@@ -607,6 +711,12 @@ def run(args):
         sampler.stop()
         # the sensor reports a moving average: the first 0.5 s of a region still hold what ran before it
         res['power'] = sampler.summary(skip_seconds=min(0.5, 0.25 * res['elapsed']))
+        reg = (res['power'] or {}).get('region')
+        if reg:                                          # the accumulators over the whole region: joules per frame, why the clock is where it is
+            if reg.get('energy_j'):
+                res['power']['energy_j_per_frame'] = round(reg['energy_j'] / (args.batch * res['steps']), 4)
+            if reg.get('throttle_residency_pct') is not None:
+                res['power']['throttle'] = reg['throttle_residency_pct']
         res['klass'] = profile_serial_step()
         if extra:
             extra(res)
@@ -652,26 +762,62 @@ def run(args):
                     np.array([x['keypoints'] for p in poses for x in p], np.int32).reshape(-1, 18, 3),
                     np.array([x['score'] for p in poses for x in p], np.float64))
 
-        def on_step(dets, feats, poses):                 # called per finished step (pipelines finish out of order
-            with lock:                                    # relative to each other; every pipeline's own steps are in order)
-                gathered.append(pack_step(dets, feats, poses) if use_dist else (dets, feats, poses))
         R = L                                                        # reader threads (pinned double buffers + upload stream each; a stream read is a single-thread ~30 ms memcpy)
         readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, R))), W, H,
                                         batch_size=args.batch, device=device_index) for i in range(R)]
         n_on_rank0 = [0]
+        n_messages = [0]
+        G = 8                                                        # steps per gather message
+        distlike = None
+        if use_dist:
+            distlike = dist if gather_group is None else _GroupDist(dist, gather_group)
+        # The ordered gather runs WHILE the region does: a gather thread per rank sends every G finished steps' results to rank 0
+        # (gather_object on the host-side gloo group; every rank runs the same k steps, so every rank issues the same
+        # ceil(k / G) collectives in the same order).  What is left for the end of the region is the last message.
+        # Without a gloo group beside RCCL the gather stays ONE message at region end (a collective on the default group from
+        # a side thread would race the barrier).
+        streamed = use_dist and (gather_group is not None or backend != 'nccl')
+        gq = queue.Queue()
+
+        def flush(chunk):
+            allr = shard.gather_results(chunk, distlike)
+            n_messages[0] += 1
+            if allr is not None:
+                n_on_rank0[0] += len(allr)
+
+        def gather_worker():
+            buf = []
+            while True:
+                item = gq.get()
+                if item is None:
+                    break
+                buf.append(item)
+                if len(buf) == G:
+                    flush(buf)
+                    buf = []
+            if buf:
+                flush(buf)
+
+        def on_step(dets, feats, poses):                 # called per finished step, in step order
+            if streamed:
+                gq.put(pack_step(dets, feats, poses))
+            else:
+                with lock:
+                    gathered.append(pack_step(dets, feats, poses) if use_dist else (dets, feats, poses))
 
         def gather_all():
-            # ONE ordered gather of the region's per-step results on rank 0 (a single collective per region keeps the ranks
-            # in lock step whatever happens inside a step); it is inside the timed region
-            if use_dist:
-                allr = shard.gather_results(list(gathered), dist if gather_group is None else _GroupDist(dist, gather_group))
-                n_on_rank0[0] = len(allr) if allr is not None else 0
+            if streamed:
+                gq.put(None)
+                gt.result(timeout=600)
+            elif use_dist:
+                flush(list(gathered))
             else:
                 n_on_rank0[0] = len(gathered)
         try:
             run_steps(2 * L, readers=readers)                                        # warm the readers' buffers (2 batches each)
             del gathered[:]
             sync()
+            gt = pool.submit(gather_worker) if streamed else None
             t0 = time.perf_counter()
             run_steps(k, readers=readers, on_step=on_step)
             tg = time.perf_counter()
@@ -690,10 +836,11 @@ def run(args):
             'value': fps(e, k), 'unit': 'frames/s', 'steps': k, 'ms_per_step': round(e / k * 1e3, 3),
             'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
             'steps_gathered_on_rank0': n_on_rank0[0],
-            'gather_s': round(gather_s, 4),                # the ONE ordered gather of the region's results on rank 0 (this rank's wait included)
+            'gather_messages': n_messages[0],
+            'gather_tail_s': round(gather_s, 4),           # what the ordered gather still takes once the last step is done (this rank's wait included)
             'what': 'same workload, every batch read from a raw rgb24 byte stream in host memory into pinned buffers and '
                     'uploaded by video.RawVideoReader (one reader thread + upload stream per pipeline, overlapped with '
-                    'compute), the per-step results of all ranks gathered on rank 0 inside the timed region; stream reads are single-thread host memcpys '
+                    'compute), the per-step results of all ranks gathered on rank 0 by a gather thread while the region runs (8 steps per message); stream reads are single-thread host memcpys '
                     '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or HEADLINE)
@@ -704,7 +851,7 @@ def run(args):
     #    with their power objects; if they differ by more than 2 % the un-zeroed one IS the headline (`value`).
     legs = {'decoder_pose_weights': head}
     headline_leg = 'decoder_pose_weights'
-    if (args.side and not (args.serial or args.join_steps)) or os.environ.get('TA_BENCH_RANDOM_LEG'):
+    if (args.side and args.full and not (args.serial or args.join_steps)) or os.environ.get('TA_BENCH_RANDOM_LEG'):
         from terran_amd import synth, weights
         work.update(sd_p=weights.make_openpose_state(), frames=synth.frames(900 + rank, args.batch, H, W))
         try:
@@ -742,7 +889,7 @@ def run(args):
     others = {}
     primary_drift = None
     if args.side:
-        for prec in ('f32', 'f16x3', 'bf16x3', 'f16', 'f16x2', 'bf16'):
+        for prec in (('f32', 'f16x3', 'bf16x3', 'f16', 'f16x2', 'bf16') if args.full else SIDE_PRECISIONS):
             if prec != primary:
                 r2 = run_mode(prec, max(L, args.steps // 2), min_seconds=args.side_seconds)
                 others[prec] = {'value': fps(r2['elapsed'], r2['steps']), 'steps': r2['steps'],
@@ -760,7 +907,7 @@ def run(args):
 
     # SURVEY.md 8(d) quotes the workload at F = 1 and F = 4 faces per frame: same pipeline, headline precision
     other_faces = {}
-    if args.side:
+    if args.side and args.full:
         for nf in (1, 4):
             if nf != F:
                 face_state['F'] = nf
@@ -844,7 +991,11 @@ def run(args):
                                if headline_leg == 'decoder_pose_weights' else
                                'pose weights WITHOUT structured zeros (weights.make_openpose_state) on frames of noise: this leg differs by more '
                                'than 2 % from the decoder-weights leg (`value_decoder_pose_weights`), so it is the headline'),
+                'workload_short': 'BASELINE configs[4]: 1080p detect+embed+pose; Detection(short_side=416) + Recognition(top-%d) + '
+                                  'Estimation(short_side=184); %d frames per GPU per step resident in HBM; random-init weights' % (F, args.batch),
                 'headline_leg': headline_leg,
+                # `value`: every step runs on the SAME resident batch (no upload in the region); `value_ingest`: a fresh upload per step
+                'resident_batch_reused': True,
                 'precision': primary,
                 'frames_per_gpu_step': args.batch,
                 'faces_per_frame': F,
@@ -909,6 +1060,9 @@ def run(args):
         if 'bf16' in others:                                         # BASELINE configs[1]'s "bf16": the throughput mode, with its measured drift
             result['value_bf16'] = others['bf16']['value']
             result['decision_drift_bf16'] = others['bf16'].get('decision_drift')
+        if 'f16x2' in others:                                        # opt-in tolerance mode: the embedder on two of the three products
+            result['value_f16x2'] = others['f16x2']['value']
+            result['ms_per_step_f16x2'] = others['f16x2']['ms_per_step']
         if 'f16' in others:                                          # opt-in tolerance mode for the embedder alone (see DTYPES['f16'])
             result['value_f16_embedder'] = others['f16']['value']
             result['ms_per_step_f16_embedder'] = others['f16']['ms_per_step']
@@ -938,7 +1092,8 @@ def run(args):
     pool.shutdown()
     if rank == 0 and world == 1 and args.side:
         try:
-            result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'])
+            result['per_model'] = per_model(runtime.get_context(device_index), [primary, 'f32'] if primary != 'f32' else ['f32'],
+                                            embedder_modes=args.full)
         except Exception as ex:
             import traceback
             traceback.print_exc()
@@ -982,7 +1137,7 @@ C2_BYTES_PER_IMAGE, C2_WEIGHT_BYTES = 56.3e6, 0.84e6
 C3_GFLOP_PER_CROP, C4_GFLOP_PER_IMAGE, C2_GFLOP_PER_IMAGE = 24.1792, 484.634, 1.9623
 
 
-def per_model(ctx, precisions, reps=8):
+def per_model(ctx, precisions, reps=8, embedder_modes=False):
     from terran_amd import arcface, openpose, retinaface, runtime, synth, weights
 
     def timed(fn, reps, warm=2):
@@ -1064,7 +1219,7 @@ def per_model(ctx, precisions, reps=8):
             'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'achieved': round(tf, 1), 'frac': round(tf / peak, 4),
                          'mfma_issue_frac': round(tf * emb_factor / peak, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP}}
         arc.model.free()
-        for alt in ([m for m in ('f16x2', 'f16x3', 'f16') if m != prec] if prec in ('f16x2', 'f16x3', 'f16') else []):     # the embedder's other modes beside it
+        for alt in ([m for m in ('f16x2', 'f16x3', 'f16') if m != prec] if embedder_modes and prec in ('f16x2', 'f16x3', 'f16') else []):     # the embedder's other modes beside it
             arc = arcface.ArcFace(device=ctx.device_id, state=sd_a, precision=alt, ctx=ctx)
             dt, prof = timed(lambda: arc.embed_crops(c3), max(2, reps // 2))
             tf = prof['conv_igemm'][2] / max(prof['conv_igemm'][0], 1e-9) / 1e9
@@ -1073,7 +1228,7 @@ def per_model(ctx, precisions, reps=8):
                 'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0, 'achieved': round(tf, 1), 'frac': round(tf / 2500.0, 4),
                              'mfma_issue_frac': round(tf * {'f16': 1, 'f16x2': 2}.get(alt, 3) / 2500.0, 4), 'algorithmic_gflop_per_crop': C3_GFLOP_PER_CROP,
                              'note': 'f16: one f16 MFMA per product on 2-byte half-float activations, embeddings 3.3e-4 (wild-statistics weights 1.8e-3) vs the 1e-3 bar; '
-                                     'f16x2 (default): two per product, (w_hi + w_lo) * x_hi, embeddings 1.8e-4 (8.2e-4); '
+                                     'f16x2 (opt-in, guarded at load): two per product, (w_hi + w_lo) * x_hi, embeddings 1.8e-4 (8.2e-4); '
                                      'f16x3: three per product on split-half operands, embeddings 5e-7'}}
             arc.model.free()
         pose = openpose.OpenPose(device=ctx.device_id, short_side=368, state=sd_p, precision=prec, ctx=ctx)

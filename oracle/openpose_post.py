@@ -139,9 +139,10 @@ def _linspace_trunc(a, b):
     return np.stack(pts, 0)                    # (10, Ns, Nd)
 
 
-def score_limb(pafs, limb_id, loc_src, loc_dst):
+def score_limb(pafs, limb_id, loc_src, loc_dst, debug=None):
     """pafs (38,H,W) float32 upsampled.  Returns (reg_scores (Ns,Nd) float32,
-    accept (Ns,Nd) bool)."""
+    accept (Ns,Nd) bool).  debug: a dict that receives the ten per-sample scores
+    `mid` (10,Ns,Nd) the 9-of-10 criterion looks at (tests/margins.py)."""
     cx, cy = MAP_IDX[limb_id][0] - 19, MAP_IDX[limb_id][1] - 19
     H_up = pafs.shape[1]
     d = (loc_dst[None, :, :] - loc_src[:, None, :]).astype(F32)        # (Ns,Nd,2) = (dy,dx)
@@ -163,6 +164,8 @@ def score_limb(pafs, limb_id, loc_src, loc_dst):
         reg = total / F32(NUM_MIDPOINTS) + pen
         crit1 = (mid > F32(MIDPOINT_THRESHOLD)).sum(0) > 0.8 * NUM_MIDPOINTS
         crit2 = reg > F32(0)
+    if debug is not None:
+        debug['mid'] = mid
     return reg.astype(F32), (crit1 & crit2)
 
 
@@ -190,10 +193,12 @@ def greedy_match(reg, accept):
 # ----------------------------------------------------------------------------
 # assembly
 # ----------------------------------------------------------------------------
-def assemble_humans(peaks, connections_per_limb):
+def assemble_humans(peaks, connections_per_limb, debug=None):
     """peaks: list[18] of (locs, scores); connections_per_limb: list[19] of None
     (limb missing: an endpoint part has no peaks) or list of (i, j, score).
-    Returns (peaks_by_id (P,3) float64 [y,x,score], humans (M,20) float64)."""
+    Returns (peaks_by_id (P,3) float64 [y,x,score], humans (M,20) float64).
+    debug: a dict that receives `unfiltered`, the humans before the final filter
+    (tests/margins.py: how far each was from the 0.4 bar)."""
     offs = np.cumsum([0] + [p[0].shape[0] for p in peaks])
     rows = [(float(y), float(x), float(s)) for locs, scs in peaks for (y, x), s in zip(locs, scs)]
     peaks_by_id = np.array(rows, dtype=np.float64).reshape(-1, 3)
@@ -233,6 +238,8 @@ def assemble_humans(peaks, connections_per_limb):
                 hm[19] = 2
                 hm[18] = (0 + peaks_by_id[int(a), 2] + peaks_by_id[int(b), 2]) + s
                 humans.append(hm)
+    if debug is not None:
+        debug['unfiltered'] = [h.copy() for h in humans]
     kept = [h for h in humans if not (h[19] < 4 or h[18] / h[19] < HUMAN_THRESHOLD)]
     humans = np.array(kept, dtype=np.float64).reshape(-1, 20)
     return peaks_by_id, humans

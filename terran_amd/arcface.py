@@ -1,4 +1,8 @@
 """`ArcFace` -- drop-in for terran/face/recognition/arcface/wrapper.py:102-184 on MI355X."""
+import os
+import threading
+import warnings
+
 import numpy as np
 
 from . import lib, pack, runtime
@@ -45,15 +49,101 @@ def align_matrix(landmarks):
     return align_matrices(np.asarray(landmarks)[None])[0]
 
 
+# -- the load-time guard of the two-product mode ------------------------------------------------------------------------
+# 'f16x2' feeds every activation into the contractions as its hi half (11 bits).  How far that moves the unit embedding is a
+# property of the WEIGHTS (1.8e-4 on the seeded ones, 8.2e-4 on the wild-statistics ones, never measured on a trained
+# checkpoint), and the reference's contract is fp32 (arcface/wrapper.py:166-176).  So the mode is not taken on trust: when
+# an 'f16x2' embedder is loaded, GUARD_CROPS fixed calibration crops are embedded in 'f16x2' and in 'f16x3' (float32-grade)
+# and the two-product program is kept only if no unit-embedding component moves by more than GUARD_TOL -- half of
+# north_star's 1e-3 bar.  Otherwise the model IS the 'f16x3' one, with one warning.
+GUARD_TOL = 5e-4
+GUARD_CROPS = 32
+_guard_memo = {}                 # id(state dict) -> (state dict, decision): dict states (tests, bench, pipeline lanes)
+_guard_lock = threading.Lock()
+
+
+def calibration_crops(n=GUARD_CROPS):
+    """(n,3,112,112) uint8 BGR crops, fixed (seeds 4242 / 4243): half smooth colour fields + sensor-like noise
+    (terran_amd.synth.frames: the statistics of an aligned face crop as far as the first convolutions care), half uniform
+    byte noise (the worst input for an 11-bit activation path: every frequency at full amplitude)."""
+    from . import synth
+    smooth = synth.frames(4242, n - n // 2, 112, 112).transpose(0, 3, 1, 2)
+    noise = np.random.default_rng(4243).integers(0, 256, (n // 2, 3, 112, 112), dtype=np.uint8)
+    return np.ascontiguousarray(np.concatenate([smooth, noise]))
+
+
+def guard_f16x2(ctx, state, tol=None):
+    """-> {'selected': 'f16x2' | 'f16x3', 'max_abs_diff': float, 'tol': float, 'crops': int} for these weights.
+    Cached: in the f16x2 repack cache of a checkpoint file (Program.extra, rewritten once), per state-dict object otherwise."""
+    tol = GUARD_TOL if tol is None else tol
+    prog2 = runtime.packed_program('arcface', state, 'f16x2')
+    hit = prog2.extra.get('f16x2_guard')
+    if hit and hit.get('tol') == tol and hit.get('crops') == GUARD_CROPS:
+        return hit
+    sd = state if isinstance(state, dict) else None
+    if sd is not None:
+        with _guard_lock:
+            m = _guard_memo.get((id(sd), tol))
+            if m is not None and m[0] is sd:
+                return m[1]
+    crops = calibration_crops()
+    outs = {}
+    for mode, prog in (('f16x2', prog2), ('f16x3', runtime.packed_program('arcface', state, 'f16x3'))):
+        model = lib.Model(ctx, prog)
+        try:
+            out = np.empty((len(crops), 512), np.float32)
+            try:
+                ctx.check(ctx.lib.ta_arcface_embed_crops(model.h, lib.ptr(crops), len(crops), 1, lib.ptr(out)))
+            except lib.TerranAmdError as e:
+                if e.code != lib.E_RANGE:
+                    raise
+                out = None                      # the calibration crops leave the half-float range: not a mode to opt into
+            outs[mode] = out
+        finally:
+            model.free()
+    if outs['f16x2'] is None or outs['f16x3'] is None:
+        diff = float('inf')
+    else:
+        diff = float(np.abs(outs['f16x2'] - outs['f16x3']).max())
+    res = {'selected': 'f16x2' if diff <= tol else 'f16x3', 'max_abs_diff': diff if np.isfinite(diff) else None, 'tol': tol,
+           'crops': GUARD_CROPS}
+    prog2.extra['f16x2_guard'] = res
+    cache = getattr(prog2, '_cache_path', None)
+    if cache:
+        try:
+            prog2.save_cache(cache)
+        except OSError:
+            pass                                # read-only checkpoint dir: calibrate again next time
+    if sd is not None:
+        with _guard_lock:
+            _guard_memo[(id(sd), tol)] = (sd, res)
+            while len(_guard_memo) > 8:
+                _guard_memo.pop(next(iter(_guard_memo)))
+    return res
+
+
 class ArcFace(runtime.RangeFallback):
 
-    def __init__(self, device=None, image_side=112, state=None, ctx=None, precision=None):
+    def __init__(self, device=None, image_side=112, state=None, ctx=None, precision=None, guard=None):
+        """guard: run the load-time calibration of precision='f16x2' (guard_f16x2; None = yes unless $TERRAN_AMD_F16X2_UNGUARDED)."""
         if image_side != 112:
             raise ValueError('the ArcFace-R100 head is a 25088->512 linear layer: image_side must be 112')
         self.device = device
         self.precision = runtime.resolve_precision(precision)
         self.image_side = image_side
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
+        self.guard = None
+        if guard is None:
+            guard = not os.environ.get('TERRAN_AMD_F16X2_UNGUARDED')
+        if self.precision == 'f16x2' and guard:
+            self.guard = guard_f16x2(self.ctx, state)
+            if self.guard['selected'] != 'f16x2':
+                warnings.warn('terran_amd: precision="f16x2" moves the unit embedding of these ArcFace weights by %s on the %d '
+                              'calibration crops (limit %g): the embedder runs in "f16x3" (float32-grade) instead'
+                              % ('more than the half-float range allows' if self.guard['max_abs_diff'] is None
+                                 else '%.2e' % self.guard['max_abs_diff'], self.guard['crops'], self.guard['tol']),
+                              RuntimeWarning, stacklevel=2)
+                self.precision = 'f16x3'
         self.model = lib.Model(self.ctx, runtime.packed_program('arcface', state, self.precision))
         self._init_fallback('arcface', state)
 

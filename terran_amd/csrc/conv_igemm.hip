@@ -2429,7 +2429,8 @@ int ta_debug_kernel_work(ta_ctx* ctx, char* csv, size_t capacity, int reset) {
              t == ctx->kernel_ms.end() ? 0.0 : t->second);
     out += line;
   }
-  if (reset && ctx->pending.empty()) {               // (pending events point at the keys)
+  if (reset) {
+    ta_drain_profile(ctx);                           // pending events point at the keys: read them out first
     ctx->kernel_work.clear();
     ctx->kernel_ms.clear();
   }

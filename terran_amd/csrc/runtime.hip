@@ -80,6 +80,7 @@ static hipEvent_t get_event(ta_ctx* ctx) {
 }
 
 ta_prof_scope::ta_prof_scope(ta_ctx* c, int k, double w) : ctx(c), klass(k), work(w) {
+  ctx->cur_kernel = nullptr;          // whatever launch noted its instance last belongs to an EARLIER scope (also while profiling was off)
   if (!ctx->profiling) return;
   a = get_event(ctx);
   b = get_event(ctx);
@@ -87,7 +88,10 @@ ta_prof_scope::ta_prof_scope(ta_ctx* c, int k, double w) : ctx(c), klass(k), wor
 }
 
 ta_prof_scope::~ta_prof_scope() {
-  if (!ctx->profiling || !a || !b) return;
+  if (!ctx->profiling || !a || !b) {
+    ctx->cur_kernel = nullptr;
+    return;
+  }
   (void)hipEventRecord(b, ctx->stream);
   ctx->pending.push_back({a, b, klass, ctx->cur_kernel});
   ctx->cur_kernel = nullptr;
@@ -95,7 +99,7 @@ ta_prof_scope::~ta_prof_scope() {
   ctx->prof[klass].work += work;
 }
 
-static void drain_profile(ta_ctx* ctx) {
+void ta_drain_profile(ta_ctx* ctx) {
   if (ctx->pending.empty()) return;
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& pe : ctx->pending) {
@@ -138,6 +142,15 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return TA_E_DEVICE;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return TA_E_DEVICE;   // this library is gfx950-only
   if (hipSetDevice(device_id) != hipSuccess) return TA_E_DEVICE;
+  // Host threads BLOCK in their stream syncs instead of spinning: every task thread (detect / embed / pose per lane, 12+ per
+  // GPU) ends each call in hipStreamSynchronize, and the runtime's default wait polls the completion signal from user space for
+  // as long as the stream runs -- ~6 cores busy per rank doing nothing (0.085 CPU-seconds per 13.5 ms step, round 5).  With
+  // this flag the runtime polls for ~100 us (short kernels still return at once) and then sleeps on the signal's interrupt.
+  // TERRAN_AMD_SPIN_WAIT=1 keeps the spinning wait (latency probes).
+  {
+    const char* spin = getenv("TERRAN_AMD_SPIN_WAIT");
+    if (!(spin && spin[0] && spin[0] != '0')) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+  }
   ta_ctx* ctx = new ta_ctx();
   ctx->device = device_id;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -168,7 +181,7 @@ void ta_ctx_destroy(ta_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  drain_profile(ctx);
+  ta_drain_profile(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -211,7 +224,7 @@ int ta_ctx_sync(ta_ctx* ctx) {
 int ta_profile_enable(ta_ctx* ctx, int on) {
   ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
-  if (!on) drain_profile(ctx);
+  if (!on) ta_drain_profile(ctx);
   ctx->profiling = on != 0;
   return TA_OK;
 }
@@ -219,7 +232,7 @@ int ta_profile_enable(ta_ctx* ctx, int on) {
 int ta_profile_reset(ta_ctx* ctx) {
   ta_enter(ctx);
   if (!ctx) return TA_E_INVALID;
-  drain_profile(ctx);
+  ta_drain_profile(ctx);
   for (auto& p : ctx->prof) p = ta_prof_class();
   return TA_OK;
 }
@@ -227,7 +240,7 @@ int ta_profile_reset(ta_ctx* ctx) {
 int ta_profile_read(ta_ctx* ctx, int klass, double* ms, int64_t* launches, double* work) {
   ta_enter(ctx);
   if (!ctx || klass < 0 || klass > 3) return TA_E_INVALID;
-  drain_profile(ctx);
+  ta_drain_profile(ctx);
   if (ms) *ms = ctx->prof[klass].ms;
   if (launches) *launches = ctx->prof[klass].launches;
   if (work) *work = ctx->prof[klass].work;

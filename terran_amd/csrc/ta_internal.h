@@ -234,6 +234,8 @@ struct ta_prof_scope {
   ~ta_prof_scope();
 };
 
+void ta_drain_profile(ta_ctx* ctx);   // runtime.hip: waits for the stream and adds every pending event pair to the class / instance times
+
 struct ta_frames {
   ta_ctx* ctx;
   int n, h, w;

@@ -204,7 +204,7 @@ class Detection:
             # same float32 element-wise arithmetic as the reference's per-face code (face/detection/__init__.py:59-84)
             b = np.around(boxes / scales).astype(np.int32)
             l = np.around(lmks / scales).astype(np.int32)
-            out = results.detections(counts, b, l, scores)
+            out = results.detections(counts, b, l, scores, lazy=self._model_kw.get('lazy_results') or None)
             return out[0] if expanded else out
         # un-pad and un-scale one image at a time (same element-wise arithmetic and dtypes as the
         # reference's per-face code, face/detection/__init__.py:59-84,141-176), then hand out row views

@@ -56,7 +56,8 @@ _SOURCE_TAG = []
 
 def source_tag():
     """Short hash of the packer's own sources: a repack cache written by another version of pack.py / arch.py is not read.
-    Computed once per process; an install without the .py files (pyc-only, zip) falls back to the blob version alone."""
+    Computed once per process; an install without the .py files (pyc-only, zip) has nothing to hash: it returns None and
+    runtime.packed_program then runs WITHOUT the on-disk cache (two such installs of different packers would share one key)."""
     if not _SOURCE_TAG:
         import hashlib
         h = hashlib.sha256()
@@ -67,7 +68,7 @@ def source_tag():
                     h.update(fh.read())
             _SOURCE_TAG.append(h.hexdigest()[:10])
         except OSError:
-            _SOURCE_TAG.append('nosrc')
+            _SOURCE_TAG.append(None)
     return _SOURCE_TAG[0]
 
 
@@ -196,6 +197,7 @@ class Program:
         self.wchunks = []
         self.wbytes = 0
         self.names = {}        # debug taps: name -> (tensor, ch_off, ch)
+        self.extra = {}        # JSON-able notes that travel with the repack cache (save_cache / from_cache)
         self.input_tensor = None
         self.outputs = []
         self.f32_only = set()
@@ -547,14 +549,16 @@ class Program:
         self = cls(meta['kind'], meta['precision'])
         self.names = {k: tuple(v) for k, v in meta['names'].items()}
         self.outputs = meta['outputs']
+        self.extra = dict(meta.get('extra') or {})
         self._blob = blob
         return self
 
     def save_cache(self, path):
         import json
         import os
+        # `extra`: decisions taken about this program after packing (arcface.guard_f16x2's calibration result) -- kept with the blob
         meta = json.dumps({'kind': self.kind, 'precision': self.precision, 'names': self.names,
-                           'outputs': [int(o) for o in self.outputs]}).encode()
+                           'outputs': [int(o) for o in self.outputs], 'extra': getattr(self, 'extra', {})}).encode()
         tmp = path + '.tmp.%d' % os.getpid()
         with open(tmp, 'wb') as f:
             f.write(b'TAMCACHE' + len(meta).to_bytes(8, 'little') + meta + self.blob())

@@ -27,6 +27,7 @@ its id, results of an abandoned generation are dropped, its queued work is skipp
 feeder.  After a lane error the pipeline is dead: `run()` raises at once instead of waiting for results that cannot come.
 """
 import itertools
+import collections
 import queue
 import threading
 import time
@@ -63,25 +64,46 @@ class _Embedder:
         self.min_crops, self.max_crops, self.max_wait = int(min_crops), int(max_crops), float(max_wait)
         self.ctx = runtime.new_context(self.device)
         self.rec = make_rec(self.device, self.ctx)
-        self.q = queue.Queue()
+        # the worker's inbox: a deque and the `upstream` count under ONE condition -- deliver() / skip() wake the worker, which
+        # otherwise sleeps (no timed polling under the GIL while lanes are busy)
+        self.items = collections.deque()
+        self.cv = threading.Condition()
         self.upstream = 0                                   # shards uploaded on this device whose detections have not arrived here yet
-        self._up_lock = threading.Lock()
         self.launches = self.crops = 0                      # statistics: crops per launch = crops / launches
         self.thread = threading.Thread(target=self._guard, daemon=True, name='terran_amd-embed')
         self.thread.start()
 
     def announce(self):
         """A lane uploaded a shard: its detections WILL arrive (deliver / skip)."""
-        with self._up_lock:
+        with self.cv:
             self.upstream += 1
 
     def deliver(self, item):
-        self.q.put(item)
-        self.skip()
+        with self.cv:
+            self.items.append(item)
+            self.upstream -= 1
+            self.cv.notify()
 
     def skip(self):
-        with self._up_lock:
+        """An announced shard will NOT deliver (no faces, abandoned run, or its lane failed)."""
+        with self.cv:
             self.upstream -= 1
+            self.cv.notify()
+
+    def _take(self, timeout=None, while_upstream=False):
+        """The next item; None once `timeout` seconds have passed or (while_upstream) nothing is between upload and detect on
+        this device any more -- an interactive / tracking loop that feeds one batch at a time: no more faces are coming,
+        waiting would only add `max_wait` to every batch."""
+        end = None if timeout is None else time.perf_counter() + timeout
+        with self.cv:
+            while not self.items:
+                if while_upstream and self.upstream <= 0:
+                    return None
+                left = None if end is None else end - time.perf_counter()
+                if left is not None and left <= 0:
+                    return None
+                self.cv.wait(left)
+            return self.items.popleft()
 
     def _guard(self):
         try:
@@ -89,18 +111,16 @@ class _Embedder:
             self._loop()
         except BaseException as e:                              # noqa: BLE001  (re-raised in the consumer)
             self.fail(e)
-            while True:                                         # what is still queued keeps its frames in HBM otherwise
-                try:
-                    it = self.q.get_nowait()
-                except queue.Empty:
-                    break
+            with self.cv:                                       # what is still queued keeps its frames in HBM otherwise
+                left, self.items = list(self.items), collections.deque()
+            for it in left:
                 if it is not _STOP:
                     it[4].release()
 
     def _loop(self):
         carry = None
         while True:
-            first = carry if carry is not None else self.q.get()
+            first = carry if carry is not None else self._take()
             carry = None
             if first is _STOP:
                 return
@@ -108,14 +128,8 @@ class _Embedder:
             deadline = time.perf_counter() + self.max_wait
             stop = False
             while n < self.min_crops:                           # more shards, until enough crops or the wait is over
-                left = deadline - time.perf_counter()
-                try:
-                    # nothing between upload and detect on this device (an interactive / tracking loop that feeds one batch
-                    # at a time): no more faces are coming, waiting would only add `max_wait` to every batch
-                    nxt = self.q.get(timeout=min(left, 0.001)) if left > 0 else self.q.get_nowait()
-                except queue.Empty:
-                    if left > 0 and self.upstream > 0:
-                        continue
+                nxt = self._take(deadline - time.perf_counter(), while_upstream=True)
+                if nxt is None:
                     break
                 if nxt is _STOP:
                     stop = True
@@ -143,7 +157,9 @@ class _Embedder:
                 it[4].release()
 
     def close(self):
-        self.q.put(_STOP)
+        with self.cv:
+            self.items.append(_STOP)
+            self.cv.notify()
         self.thread.join(timeout=30)
         if not self.thread.is_alive():
             wrapper = self.rec.model
@@ -201,6 +217,10 @@ class _Lane:
                 if not own and free_resident:
                     shard.free()
                 continue
+            if self.dead:                                       # a task thread of this lane failed: nothing would take the shard
+                if not own and free_resident:                   # (and nothing must be announced to the embed worker for it)
+                    shard.free()
+                continue
             frames = self.ctx_up.upload(shard) if own else shard
             refs = _Refs(3, frames if (own or free_resident) else None)
             if self.embedder is not None:
@@ -223,8 +243,17 @@ class _Lane:
                     refs.release()
                 refs.release()
                 continue
-            dets = self.det(frames)
-            faces = pick(dets)
+            try:
+                dets = self.det(frames)
+                faces = pick(dets)
+            except BaseException:
+                # the shard was announced to the embed worker (`upstream`): a lane that dies here must take the announcement
+                # back, or every later launch of the device's embedder waits its full `max_wait` for faces that never come
+                if self.embedder is not None:
+                    self.embedder.skip()
+                    refs.release()
+                refs.release()
+                raise
             if self.embedder is None:
                 self.q_faces.put(faces)
             elif not any(len(f) for f in faces):                # no face in the shard: nothing to wait for, nothing to launch

@@ -3,14 +3,23 @@
 `detections(counts, boxes, landmarks, scores)` -> list[N] of list[{'bbox', 'landmarks', 'score'}]: row VIEWS into the
 arrays and numpy float32 scalars, exactly what `detections_py` below yields (retinaface/wrapper.py:228-236).
 
-The per-image lists are `LazyFaces`: a `list` subclass that creates its dicts the first time anything looks at them.  A
+By DEFAULT the per-image lists are plain `list`s of dicts, built at once (through the C module `_pyresults` when it is built):
+the reference returns plain lists, and a drop-in must survive everything callers do to them -- including C code that reads a
+list's storage directly (CPython's own `list + x` / `sum(dets, [])` with a plain list on the left, ujson, Cython `list`
+arguments), which no subclass method can intercept.
+
+OPT-IN (`detections(..., lazy=True)`, TERRAN_AMD_LAZY_RESULTS=1, the wrappers' `lazy_results=True`): the per-image lists are
+`LazyFaces`: a `list` subclass that creates its dicts the first time anything looks at them.  A
 detector call on a video batch returns thousands of detections (~11 000 per 32 1080p frames of noise through random
 weights); one dict + two array views + one numpy scalar each is ~150 ns through the C API (`_pyresults`, csrc/pyresults.c)
 and ~350 ns as a comprehension -- 0.7 - 2 ms per call with the GIL held, as long as the network itself takes on the device
 -- and most callers read a few faces per image (the pipeline's `pick_faces` reads the top F).  Until then a LazyFaces
 holds three array slices.  `len()` needs no dicts; indexing, slicing, iteration, comparison, mutation, pickling, `repr`
 and anything that goes through the sequence protocol (`list(x)`, `sorted`, `json.dumps`, `numpy.array`) fill the list first
-and then behave as the plain list they are.  TERRAN_AMD_EAGER_RESULTS=1 (or `eager(x)`) builds plain lists at once.
+and then behave as the plain list they are; `plain_list + lazy` and `sum(lazy_lists, [])` go through `__radd__` (a subclass's
+reflected slot is tried before list's own concatenation).  What stays out of reach is C code that takes the object for a
+plain list and reads `ob_item` without calling anything: it sees an empty list -- hence opt-in, for callers that know
+their consumers (the pipeline's `pick_faces` reads the top F faces of thousands).  `eager(x)` builds plain lists.
 Host glue only: no arithmetic.
 """
 import os
@@ -86,6 +95,13 @@ def _filled(name):
     return method
 
 
+def _radd(self, other):
+    # `plain_list + lazy`, `sum(lazies, [])`: list's sq_concat would copy this object's (empty) storage
+    return list.__add__(other._fill() if isinstance(other, LazyFaces) else list(other), self._fill())
+
+
+LazyFaces.__radd__ = _radd
+
 for _name in ('__getitem__', '__setitem__', '__delitem__', '__iter__', '__reversed__', '__contains__', '__eq__', '__ne__',
               '__lt__', '__le__', '__gt__', '__ge__', '__add__', '__iadd__', '__mul__', '__rmul__', '__imul__', 'append',
               'extend', 'insert', 'pop', 'remove', 'clear', 'index', 'count', 'sort', 'reverse', 'copy'):
@@ -98,8 +114,10 @@ def eager(dets):
     return [list(d) for d in dets]
 
 
-def detections(counts, boxes, landmarks, scores):
-    if os.environ.get('TERRAN_AMD_EAGER_RESULTS'):
+def detections(counts, boxes, landmarks, scores, lazy=None):
+    if lazy is None:
+        lazy = bool(os.environ.get('TERRAN_AMD_LAZY_RESULTS')) and not os.environ.get('TERRAN_AMD_EAGER_RESULTS')
+    if not lazy:
         return detections_eager(counts, boxes, landmarks, scores)
     out, o = [], 0
     for c in (counts.tolist() if hasattr(counts, 'tolist') else counts):

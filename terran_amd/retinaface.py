@@ -8,8 +8,9 @@ from . import lib, pack, results, runtime
 
 class RetinaFace(runtime.RangeFallback):
 
-    def __init__(self, device=None, nms_threshold=0.4, state=None, ctx=None, precision=None):
+    def __init__(self, device=None, nms_threshold=0.4, state=None, ctx=None, precision=None, lazy_results=False):
         self.device = device
+        self.lazy_results = lazy_results               # opt-in: per-image results.LazyFaces instead of plain lists (results.py)
         self.precision = runtime.resolve_precision(precision)
         self.nms_threshold = nms_threshold
         self.ctx = ctx if ctx is not None else runtime.get_context(device)     # ctx: an extra stream on the same GPU
@@ -46,7 +47,7 @@ class RetinaFace(runtime.RangeFallback):
 
     def call_frames(self, frames, threshold=0.5):
         """frames: lib.Frames (N,H,W,3) at network resolution, resident in HBM."""
-        return results.detections(*self.detect_arrays(frames, threshold))
+        return results.detections(*self.detect_arrays(frames, threshold), lazy=self.lazy_results or None)
 
     def call(self, images, threshold=0.5):
         """images: (N,H,W,3) uint8 RGB ndarray -> list[N] of list[{'bbox','landmarks','score'}] in

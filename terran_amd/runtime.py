@@ -63,20 +63,23 @@ def resolve_state(kind, state):
     raise ValueError('Checkpoint not found.')     # same error as terran/checkpoint.py:242,310
 
 
-DEFAULT_PRECISION = 'f16x2'
+DEFAULT_PRECISION = 'f16x3'
 
 
 def resolve_precision(precision=None):
     """A precision names the arithmetic of all three networks:
       'f32'    every conv on the exact-f32 MFMA (the like-for-like arithmetic);
-      'f16x3'  split-half MFMA everywhere: operands x = hi + lo (two IEEE halfs, 22 bits), three MFMAs per product, float32-grade
-               results (the detector's raw-pixel front stays exact f32, its deep base and refiner run split-half); half-float
-               range: TA_E_RANGE -> the wrappers re-run the batch on an exact-f32 twin (RangeFallback below);
-      'f16x2'  THE DEFAULT ($TERRAN_AMD_PRECISION overrides): the detector and the pose network -- everything that takes a discrete
+      'f16x3'  THE DEFAULT ($TERRAN_AMD_PRECISION overrides): split-half MFMA everywhere: operands x = hi + lo (two IEEE halfs, 22
+               bits), three MFMAs per product, float32-grade results (embeddings to ~1e-6 of the oracle, decisions at float32's own
+               rate; the detector's raw-pixel front stays exact f32, its deep base and refiner run split-half); half-float range:
+               TA_E_RANGE -> the wrappers re-run the batch on an exact-f32 twin (RangeFallback below);
+      'f16x2'  opt-in tolerance mode for the EMBEDDER: the detector and the pose network -- everything that takes a discrete
                decision -- exactly as in 'f16x3' (the same packed programs, bit for bit); the embedder, whose only bar is 1e-3 on
                the unit-norm embedding, on two of the three products, (w_hi + w_lo) * x_hi: weights and the shortcut trunk keep 22
                bits, an activation enters a contraction as its hi half.  Measured 1.8e-4 (seeded weights) / 8.2e-4 (wild-statistics
-               weights) worst component against the oracle, cosine distance 1.6e-6 (tests/probe_embedder_modes.py);
+               weights) worst component against the oracle (tests/probe_embedder_modes.py) -- which is why the mode is GUARDED:
+               arcface.guard_f16x2 embeds 32 fixed calibration crops in both modes when the model is loaded and keeps 'f16x3'
+               (one warning) when they differ by more than 5e-4; the decision is cached with the repack cache;
       'f16'    opt-in: the embedder on ONE MFMA per product and 2-byte activations (3.3e-4 / 1.8e-3: outside the bar on the wild weights);
       'bf16x3' split-bf16 (16-bit operands, float32 range); 'bf16' throughput mode outside the 1e-3 parity bar."""
     p = precision or os.environ.get('TERRAN_AMD_PRECISION', DEFAULT_PRECISION)
@@ -133,7 +136,7 @@ def packed_program(kind, state, precision):
     elif isinstance(state, (str, os.PathLike)):
         path = state
     switches = pack.active_switches()
-    if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE') or switches:
+    if path is None or os.environ.get('TERRAN_AMD_NO_PACK_CACHE') or switches or pack.source_tag() is None:
         # dict states (tests, bench, StreamPipeline's lanes): many models of one process are built from the SAME dict --
         # pack it once (a pack is seconds of numpy work; 16 lanes x 3 networks would spend a minute on it)
         sd = resolve_state(kind, state)
@@ -155,16 +158,23 @@ def packed_program(kind, state, precision):
                                         pack.BLOB_VERSION, pack.source_tag())
     if os.path.exists(cache):
         try:
-            return pack.Program.from_cache(cache)
+            prog = pack.Program.from_cache(cache)
+            prog._cache_path = cache
+            return prog
         except Exception:
             pass                                    # unreadable cache: repack below
     prog = packer(weights.load_state(path), precision)
+    prog._cache_path = cache
     try:
         prog.save_cache(cache)
-        # repack caches of this checkpoint and precision written for another file state / blob version / packer: orphans now
+        # repack caches of this checkpoint and precision written for ANOTHER STATE OF THE FILE (size / mtime differ): orphans
+        # now.  Caches of the same file state under another blob version / pack hash belong to another install sharing
+        # $TERRAN_HOME and stay (two versions would otherwise delete each other's caches on every cold start).
         import glob
-        for old in glob.glob('%s.%s.*.tam' % (glob.escape(os.path.splitext(str(path))[0]), precision)):
-            if old != cache:
+        stem = os.path.splitext(str(path))[0]
+        mine = '%d.%d.' % (st.st_size, int(st.st_mtime))
+        for old in glob.glob('%s.%s.*.tam' % (glob.escape(stem), precision)):
+            if old != cache and not old[len(stem) + len(precision) + 2:].startswith(mine):
                 try:
                     os.unlink(old)
                 except OSError:

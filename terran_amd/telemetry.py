@@ -56,17 +56,110 @@ def sample(hw):
     return row
 
 
-class PowerSampler:
-    """Background thread reading the sensors every `period` seconds between start() and stop()."""
+# -- accumulating counters through the SMI library -------------------------------------------------------------------------
+# hwmon's power1_average is the firmware's moving average of the socket power.  Two things it cannot say: how many JOULES a
+# region cost (the figure that decides between kernel variants once the step sits at the power cap: DESIGN section 4), and
+# WHY the clock is where it is.  The firmware keeps accumulators for both (gpu_metrics: `energy_accumulator`, and per throttler
+# a residency counter that advances, in units of `accumulation_counter`, while that limiter holds the clock down: PPT = package
+# power tracking, socket / VR / HBM thermal, PROCHOT).  libamd_smi reads them; its Python package ships with ROCm under
+# /opt/rocm/share/amd_smi (not on sys.path by default).  Everything here returns None when the library, the driver or a
+# field is missing.
+_SMI = {}
+_RESIDENCIES = ('ppt_residency_acc', 'socket_thm_residency_acc', 'vr_thm_residency_acc', 'hbm_thm_residency_acc', 'prochot_residency_acc')
 
-    def __init__(self, hw, period=0.05):
+
+def _smi():
+    if 'mod' not in _SMI:
+        _SMI['mod'] = None
+        try:
+            import sys
+            for p in (os.environ.get('ROCM_PATH', '/opt/rocm') + '/share/amd_smi',):
+                if os.path.isdir(p) and p not in sys.path:
+                    sys.path.append(p)
+            import amdsmi
+            amdsmi.amdsmi_init()
+            _SMI['mod'] = amdsmi
+        except Exception:                      # no library / no driver / no permission: telemetry is optional
+            _SMI['mod'] = None
+    return _SMI['mod']
+
+
+class SmiCounters:
+    """Energy and throttler-residency accumulators of the GPU at PCI address `bdf`: `read()` -> one reading (dict),
+    `SmiCounters.delta(a, b)` -> what a region between two readings cost."""
+
+    def __init__(self, bdf):
+        self.handle = None
+        m = _smi() if bdf else None
+        if m is None:
+            return
+        try:
+            for h in m.amdsmi_get_processor_handles():
+                if str(m.amdsmi_get_gpu_device_bdf(h)).lower() == bdf.lower():
+                    self.handle = h
+                    break
+        except Exception:
+            self.handle = None
+
+    def read(self):
+        if self.handle is None:
+            return None
+        m = _smi()
+        row = {'t': time.perf_counter()}
+        try:
+            e = m.amdsmi_get_energy_count(self.handle)
+            acc = e.get('energy_accumulator', e.get('power'))
+            row['energy_uj'] = float(acc) * float(e.get('counter_resolution', 15.259))
+        except Exception:
+            pass
+        try:
+            g = m.amdsmi_get_gpu_metrics_info(self.handle)
+            for k in _RESIDENCIES + ('accumulation_counter', 'throttle_status', 'indep_throttle_status'):
+                v = g.get(k)
+                if isinstance(v, int) and v not in (0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF):
+                    row[k] = v
+        except Exception:
+            pass
+        return row if len(row) > 1 else None
+
+    @staticmethod
+    def delta(a, b):
+        """{'seconds', 'energy_j', 'power_w_from_energy', 'throttle_residency_pct': {limiter: % of the region it was active},
+        'throttle_status'} between two readings (keys the box does not report are absent); None without readings."""
+        if not a or not b:
+            return None
+        out = {'seconds': round(b['t'] - a['t'], 4)}
+        if 'energy_uj' in a and 'energy_uj' in b and b['energy_uj'] >= a['energy_uj']:
+            out['energy_j'] = round((b['energy_uj'] - a['energy_uj']) * 1e-6, 2)
+            if out['seconds'] > 0:
+                out['power_w_from_energy'] = round(out['energy_j'] / out['seconds'], 1)
+        ticks = b.get('accumulation_counter', 0) - a.get('accumulation_counter', 0)
+        if ticks > 0:
+            out['throttle_residency_pct'] = {k[:-len('_residency_acc')]: round(100.0 * (b[k] - a[k]) / ticks, 2)
+                                             for k in _RESIDENCIES if k in a and k in b}
+        for k in ('throttle_status', 'indep_throttle_status'):
+            if k in b:
+                out[k] = b[k]
+        return out if len(out) > 1 else None
+
+
+class PowerSampler:
+    """Background thread reading the sensors every `period` seconds between start() and stop(); with `bdf` (the GPU's PCI
+    address) the SMI accumulators are read at start() and stop() as well (`region`: energy, throttler residencies)."""
+
+    def __init__(self, hw, period=0.05, bdf=None):
         self.hw = hw
         self.period = period
         self.rows = []
         self._stop = threading.Event()
         self._thread = None
+        self.smi = SmiCounters(bdf) if bdf else None
+        self._smi0 = None
+        self.region = None
 
     def start(self):
+        if self.smi is not None:
+            self._smi0 = self.smi.read()
         if not self.hw or self._thread:
             return self
         self._stop.clear()
@@ -84,6 +177,9 @@ class PowerSampler:
         return self
 
     def stop(self):
+        if self.smi is not None and self._smi0 is not None:
+            self.region = SmiCounters.delta(self._smi0, self.smi.read())
+            self._smi0 = None
         if self._thread:
             self._stop.set()
             self._thread.join(timeout=2.0)          # a sensor read that hangs must not hang the caller (daemon thread)
@@ -95,8 +191,10 @@ class PowerSampler:
         own: the first readings of a region still contain what ran before it).  None when nothing was sampled."""
         rows = [r for r in self.rows if r['t'] >= skip_seconds] or self.rows
         if not rows:
-            return None
+            return {'region': self.region} if self.region else None
         out = {'samples': len(rows), 'period_s': self.period}
+        if self.region:
+            out['region'] = self.region             # the WHOLE region between start() and stop() (no skip): accumulators
         for key in ('power_w', 'sclk_mhz', 'temp_c'):
             v = [r[key] for r in rows if key in r]
             if v:

@@ -261,10 +261,11 @@ def test_c5_fullsize_frame_vs_oracle(states, precision):
             n_swapped += 1
             assert abs(float(a['score']) - float(r_dets[i]['score'])) < 1e-5        # only near-tied scores trade places
         n_off += int((vec(a) != vec(r_dets[j])).sum())
-    # what this frame measures: the default mode (and the opt-in 'f16', whose detector is the same program) reproduces the
-    # oracle's list position by position; the exact-f32 detector ('f32', 'bf16x3') has 4 of its 372 near-tied scores in
-    # swapped order -- the slack above is what two float32 implementations MAY do, the bound below what they DO
-    assert n_off == 0 and n_swapped <= (0 if precision in ('f16x3', 'f16', 'f16x2') else 6), (n_swapped, n_off)
+    # margin-aware exactness (tests/margins.py): a position may hold the oracle's NEIGHBOUR only where the two scores tie within
+    # 1e-5 (asserted per swap above) -- ten times inside the 1e-4 margin below which fp32 itself does not determine the order;
+    # every other position, and every integer coordinate, is the oracle's exactly.  Measured: 0 swaps in the split-half modes, 4
+    # of 372 in the exact-f32 detector ('f32', 'bf16x3'): reported, not capped -- the per-swap margin is the assertion.
+    assert n_off == 0, (n_swapped, n_off)
     err = float(np.abs(feats - r_feats).max())
     assert len(poses) == len(r_poses) >= 3
     for a, b in zip(poses, r_poses):

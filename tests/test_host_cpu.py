@@ -433,9 +433,9 @@ def test_f16_mode_packs_half_float_tensors_and_64_channel_slabs():
 
 
 def test_f16x2_mode_is_the_f16x3_image_with_another_opcode():
-    """precision='f16x2' (the default embedder): tensors, formats, scales and every weight byte of ArcFace are f16x3's -- the
-    kernels just skip the w_hi * x_lo product -- only the ops' `prec` field differs; the detector / pose packers read the
-    mode as 'f16x3' (the same programs bit for bit), and it is what `resolve_precision()` returns by default."""
+    """precision='f16x2' (opt-in, guarded at load: arcface.guard_f16x2): tensors, formats, scales and every weight byte of ArcFace
+    are f16x3's -- the kernels just skip the w_hi * x_lo product -- only the ops' `prec` field differs; the detector / pose
+    packers read the mode as 'f16x3' (the same programs bit for bit).  The library default is the float32-grade 'f16x3'."""
     from terran_amd import pack, runtime, weights
     sd = weights.make_arcface_state()
     P2, P3 = pack.pack_arcface(sd, 'f16x2'), pack.pack_arcface(sd, 'f16x3')
@@ -451,10 +451,10 @@ def test_f16x2_mode_is_the_f16x3_image_with_another_opcode():
     assert set(ops2['prec'].tolist()) == {5}
     for packer, state in ((pack.pack_retinaface, weights.make_retinaface_state()), (pack.pack_openpose, weights.make_openpose_state())):
         assert packer(state, 'f16x2').blob() == packer(state, 'f16x3').blob()
-    assert runtime.DEFAULT_PRECISION == 'f16x2' and runtime.resolve_precision('f16x3') == 'f16x3'
+    assert runtime.DEFAULT_PRECISION == 'f16x3' and runtime.resolve_precision('f16x2') == 'f16x2'
     import os
     if not os.environ.get('TERRAN_AMD_PRECISION'):
-        assert runtime.resolve_precision() == 'f16x2'
+        assert runtime.resolve_precision() == 'f16x3'
 
 
 def test_activation_scales_follow_the_expected_magnitudes():
@@ -561,8 +561,8 @@ def test_power_sampler_reads_hwmon_files_and_is_a_noop_without_them(tmp_path):
 
 
 def test_lazy_faces_behave_as_the_lists_they_stand_for():
-    """results.detections returns per-image `LazyFaces` (a list subclass that creates its dicts on first use): every way of
-    looking at one must give what the eager list of dicts gives."""
+    """results.detections(lazy=True) (opt-in; the default is plain lists) returns per-image `LazyFaces` (a list subclass that
+    creates its dicts on first use): every way of looking at one must give what the eager list of dicts gives."""
     import copy
     import json
     import pickle
@@ -582,7 +582,18 @@ def test_lazy_faces_behave_as_the_lists_they_stand_for():
             assert x['landmarks'].shape == (5, 2)
 
     def fresh():
-        return results.detections(counts, boxes, lms, scores)
+        return results.detections(counts, boxes, lms, scores, lazy=True)
+    plain = results.detections(counts, boxes, lms, scores)                     # the default: the reference's plain lists
+    assert all(type(g) is list for g in plain) and [len(g) for g in plain] == counts.tolist()
+    for g, w in zip(plain, want):
+        same(g, w)
+    # a plain list on the LEFT (CPython's list_concat reads the right operand's storage directly): the reflected slot fills first
+    for g, w in zip(fresh(), want):
+        same([] + g, w)
+        same([w[0]] + g if w else [] + g, ([w[0]] + w) if w else w)
+    flat = sum(fresh(), [])                                                    # the flattening idiom over a batch's results
+    same(flat, [d for w in want for d in w])
+    assert len(sum(fresh(), [])) == T
     got = fresh()
     assert isinstance(got, list) and all(isinstance(g, list) for g in got)
     assert [len(g) for g in got] == counts.tolist() and [bool(g) for g in got] == [True, False, True, True]     # no dict built yet
@@ -610,7 +621,7 @@ def test_lazy_faces_behave_as_the_lists_they_stand_for():
     assert repr(fresh()[3]) == repr(want[3]) and fresh()[1] == [] and not (fresh()[1] != [])
     assert json.dumps([[float(d['score']) for d in g] for g in fresh()]) == json.dumps([[float(d['score']) for d in w] for w in want])
     assert results.eager(fresh())[0][1]['score'] == want[0][1]['score'] and type(results.eager(fresh())[0]) is list
-    lazy_empty = results.detections(np.zeros(2, np.int32), boxes[:0], lms[:0], scores[:0])
+    lazy_empty = results.detections(np.zeros(2, np.int32), boxes[:0], lms[:0], scores[:0], lazy=True)
     assert lazy_empty == [[], []] and [len(x) for x in lazy_empty] == [0, 0]
 
 
@@ -676,11 +687,86 @@ def test_embed_worker_launch_rule(monkeypatch):
     emb.announce()
     emb.announce()
     bad, waiting = shard('f', 9, frames='boom'), shard('g', 1)
-    emb.q.put(bad)
-    emb.q.put(waiting)
+    with emb.cv:                                                  # both in the inbox before the worker looks
+        emb.items.extend([bad, waiting])
+        emb.cv.notify()
     deadline = time.perf_counter() + 5
     while not errs and time.perf_counter() < deadline:
         time.sleep(0.01)
     assert errs and bad[4].released == 1
     emb.thread.join(timeout=5)
     assert waiting[4].released == 1
+    # (5) an announced shard whose lane failed takes its announcement back (skip): a fresh worker with one shard waiting and one
+    # announced launches as soon as the skip arrives, not after max_wait
+    out2 = queue.Queue()
+    emb2 = pipeline._Embedder(0, lambda dev, ctx: Rec(), out2, errs.append, live, min_crops=8, max_crops=16, max_wait=2.0)
+    emb2.announce()
+    emb2.announce()
+    t0 = time.perf_counter()
+    emb2.deliver(shard('h', 2))
+    time.sleep(0.05)
+    assert out2.empty()
+    emb2.skip()
+    assert out2.get(timeout=5)[1] == 'h' and time.perf_counter() - t0 < 1.0 and emb2.upstream == 0
+    emb2.close()
+
+
+def test_bench_line_is_compact():
+    """bench.py's stdout line is what the driver parses, and the driver keeps the LAST 8 KB of stdout: the line is built by
+    `compact_line` from the detail object and must stay under 8192 bytes whatever prose and side legs the detail carries
+    (round 5's ~25 KB line came back as `parsed: null`)."""
+    import json
+    import bench
+    prose = 'x' * 3000
+    roof = {'kernel': 'conv_igemm_split<2,4,4,3,3>', 'bound': 'mfma', 'achieved': 439.1, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.1756,
+            'traffic': 149800000, 'mfma_issue_frac': 0.527, 'launches_per_step': 38, 'avg_launch_ms': 0.2023,
+            'algorithmic_gflop_per_launch': 87.19, 'share_of_conv_time': 0.467, 'source': prose, 'traffic_source': prose,
+            'all_conv_kernels': {'note': prose, 'pmc_dominant_layers': {'a': prose}}}
+    power = {'samples': 40, 'power_w_mean': 1301.2, 'sclk_mhz_mean': 1859.0, 'cap_w': 1400.0, 'what': prose}
+    per_model = {}
+    for prec in ('f16x3', 'f32'):
+        per_model['C2 RetinaFace 32x640x640 ' + prec] = {'images_per_s': 27000.1, 'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0,
+                                                         'achieved': 1551.0, 'frac': 0.194, 'note': prose}}
+        per_model['C3 ArcFace 256x3x112x112 ' + prec] = {'images_per_s': 16000.0, 'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0,
+                                                         'achieved': 394.0, 'frac': 0.158}}
+        per_model['C4 OpenPose 16x368x656 ' + prec] = {'images_per_s': 800.0, 'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0,
+                                                       'achieved': 430.0, 'frac': 0.172}}
+    per_model['C3 ArcFace 256x3x112x112 (embedder in the f16x2 mode)'] = {'images_per_s': 1.0, 'roofline': {'note': prose}}
+    detail = {
+        'metric': 'frames/sec 1080p detect+embed+pose', 'value': 2267.123, 'unit': 'frames/s', 'n_gpus': 1, 'steps': 144, 'warmup': 6,
+        'ms_per_step': 14.115, 'timed_region_s': 2.54, 'timed_steps': 180, 'value_k_steps': 2301.5, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': bench.DTYPES['f16x3'], 'data': 'synthetic',
+        'config': {'workload': prose, 'workload_short': 'BASELINE configs[4]: 1080p detect+embed+pose', 'precision': 'f16x3',
+                   'frames_per_gpu_step': 32, 'faces_per_frame': 2, 'resident_batch_reused': True, 'detections_per_frame': 358.2,
+                   'humans_per_frame': 4.0, 'host_placement_per_rank': [prose] * 8,
+                   'host_per_rank': [{'cpu_s_per_step': 0.085, 'threads': 15, 'cores_allowed': 64}] * 8,
+                   'batches_in_flight_per_gpu': 4, 'step_overlap': prose},
+        'roofline': roof, 'roofline_f32': dict(roof, kernel='conv_igemm_pipe<0>', peak=157.3, frac=0.8),
+        'roofline_f16x3': roof, 'stage_ms_per_step': {'conv_igemm': 14.0}, 'power': power, 'power_f32': power,
+        'decision_drift': {'vs': prose, 'detections': 11461, 'detections_differ': 0, 'people': 128, 'people_differ': 0,
+                           'embedding_max_abs_diff': 1.2e-6},
+        'value_f32': 775.2, 'value_f16x2': 2377.0, 'value_ingest': 2512.3,
+        'ingest': {'value': 2512.3, 'steps': 110, 'ms_per_step': 12.7, 'gather_tail_s': 0.001, 'gather_messages': 14,
+                   'steps_gathered_on_rank0': 110, 'what': prose},
+        'other_precisions': {p: {'roofline': roof, 'power': power, 'value': 1.0} for p in ('f32', 'f16x2', 'bf16', 'f16', 'bf16x3')},
+        'other_faces_per_frame': {'1': {'value': 1.0}, '4': {'value': 2.0}}, 'per_model': per_model,
+        'cpu_baseline': {'value': 1.82, 'unit': 'frames/s', 'cores': 128, 'cpus_allowed': 128, 'kind': 'port', 'sample': prose,
+                         'stage_ms_per_frame': {'detection': 1.0}},
+    }
+    assert len(json.dumps(detail)) > 60000
+    line = bench.compact_line(detail, 'gpurun_out/bench_detail.json')
+    assert '\n' not in line and len(line) < 8192 and len(line) < 4500, len(line)
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_f32', 'value_f16x2', 'value_ingest', 'decision_drift'):
+        assert k in d, k
+    assert d['value'] == 2267.123 and len(d['dtype']) <= 200 and d['config']['resident_batch_reused'] is True
+    assert set(d['roofline']) == {'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step',
+                                  'algorithmic_gflop_per_launch', 'mfma_issue_frac', 'share_of_conv_time'}
+    assert set(d['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and len(d['cpu_baseline']['sample']) <= 160
+    assert len(d['per_model']) == 6 and all(set(v) == {'images_per_s', 'bound', 'achieved', 'unit', 'frac'} for v in d['per_model'].values())
+    assert prose[:300] not in line
+    # a failed secondary leg (its error string) must not break the line either
+    detail['per_model'] = {'error': 'RuntimeError: ' + prose}
+    detail['cpu_baseline'] = {'error': 'OSError: ' + prose}
+    assert len(bench.compact_line(detail)) < 8192
