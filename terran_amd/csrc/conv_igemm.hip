@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 // chain in (ky, kx) order exactly like dwconv3x3_kernel -- instead of DMA'd.  The 1x1 runs on the exact-f32 MFMA, or
 // (PREC_F16X3: pack.dwpw(precision='f16x3')) on the split-half MFMA with the float32 depthwise rows split in registers.
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC = PREC_F32>
-__global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
+__global__ __launch_bounds__(256, (WAVES_N * WN_TILES == 1 ? 4 : (WAVES_N * WN_TILES == 2 ? 3 : 2))) void conv_dwpw(const ta_conv_launch p) {
   // Measured alternatives (32 x 416 x 739 frames, 12 blocks): this symmetric 4-wave kernel, two workgroups per CU,
   // 541 us; 8 waves with the tap loads of slab s+1 issued ahead of the MFMAs of slab s (208 VGPRs, one workgroup per CU,
   // 306 tiles -> two rounds) 631 us.
@@ -2249,12 +2249,33 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   static const int dw_probe = getenv("TA_DWPW_PROBE") ? atoi(getenv("TA_DWPW_PROBE")) & 3 : 0;   // debug build: timing ablations
   p.probe = dw_probe;
 #endif
+  // Pixels per tile.  A block's time is ONE tile's chain (produce a slab's depthwise rows -> barrier -> MFMAs, per 32 input
+  // channels; then park and drain): on the 40 x 40 and 20 x 20 maps a 128-pixel tile gives 400 / 100 workgroups for 256 CUs,
+  // each walking 4 - 8 slabs with four pixel rows per thread.  Smaller pixel tiles shorten the chain (fewer rows per thread per
+  // slab, fewer MFMAs per wave) and put 3 - 4 workgroups on a CU to hide each other's load latencies; what they cost is the
+  // weight slab, re-read from L2 once per tile.  Same MFMA K order per output element: a layer's bits do not depend on the tile.
+  // TA_DWPW_BM = 128 / 64 / 32 pins the choice (tools).
+  static const int bm_force = getenv("TA_DWPW_BM") ? atoi(getenv("TA_DWPW_BM")) : 0;
+  int bm = 128;
+  if (p.coutp % 128 == 0) {
+    const int tiles128 = (p.M + 127) / 128 * (p.coutp / 128);
+    bm = tiles128 >= 1024 ? 128 : (tiles128 >= 256 ? 64 : 32);
+    if (bm_force == 128 || bm_force == 64 || bm_force == 32) bm = bm_force;
+  }
   if (p.prec == PREC_F16X3) {
-    if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
+    if (p.coutp % 128 == 0) {
+      if (bm == 32) return launch_dwpw_cfg<4, 1, 1, 1, PREC_F16X3>(ctx, p);
+      if (bm == 64) return launch_dwpw_cfg<2, 2, 2, 1, PREC_F16X3>(ctx, p);
+      return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
+    }
     if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F16X3>(ctx, p);
     return launch_dwpw_cfg<1, 4, 1, 1, PREC_F16X3>(ctx, p);
   }
-  if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F32>(ctx, p);
+  if (p.coutp % 128 == 0) {
+    if (bm == 32) return launch_dwpw_cfg<4, 1, 1, 1, PREC_F32>(ctx, p);
+    if (bm == 64) return launch_dwpw_cfg<2, 2, 2, 1, PREC_F32>(ctx, p);
+    return launch_dwpw_cfg<2, 2, 2, 2, PREC_F32>(ctx, p);
+  }
   if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F32>(ctx, p);
   return launch_dwpw_cfg<1, 4, 1, 1, PREC_F32>(ctx, p);
 }
