@@ -251,7 +251,8 @@ def main():
                     help='where rank 0 writes everything the run measured (the stdout line is the <= 8 KB summary of it)')
     ap.add_argument('--no-side-legs', action='store_true',
                     help='headline + ingest legs only (no other precisions / faces per frame / random-weights / per-model legs): multi-rank rehearsals')
-    ap.add_argument('--inflight', type=int, default=4, help='lanes per GPU: batches in flight, each on its own upload / detect / embed / pose streams')
+    ap.add_argument('--inflight', type=int, default=2, help='lanes per GPU: batches in flight, each on its own upload / detect / embed / pose streams '
+                    '(2 / 3 / 4 measure alike to +4 % for 2 once the host threads block in their syncs, 1 is 4.5 % slower: profiles/r06_ab_inflight.txt, r06_energy_ab.txt)')
     ap.add_argument('--serial', action='store_true',
                     help='one kernel at a time (detect, embed, pose back to back on one host thread): the mode the '
                          'rocprofv3 kernel statistics under profiles/ are taken in, so that their per-kernel averages '
@@ -353,7 +354,7 @@ def compact_line(result, detail_path=None):
         line['power'] = {k: pw[k] for k in ('power_w_mean', 'cap_w', 'sclk_mhz_mean', 'energy_j_per_frame', 'throttle') if k in pw}
     ing = r.get('ingest')
     if isinstance(ing, dict):
-        line['ingest'] = {k: ing[k] for k in ('steps', 'ms_per_step', 'gather_tail_s', 'gather_messages', 'steps_gathered_on_rank0', 'error') if k in ing}
+        line['ingest'] = {k: ing[k] for k in ('steps', 'ms_per_step', 'gather_tail_s', 'gather_after_last_rank_s', 'gather_messages', 'steps_gathered_on_rank0', 'error') if k in ing}
     pm = r.get('per_model')
     if isinstance(pm, dict):
         rows = {}
@@ -751,12 +752,21 @@ def run(args):
         gathered = []
         lock = threading.Lock()
 
+        def rows_of(per_image, key, tail, dtype):
+            """All `key` arrays of a step's dicts as ONE array: the dicts hold row VIEWS into the packed result array of the
+            batch (terran_amd.results), so the array is their common base -- no per-detection work under the GIL."""
+            total = sum(len(d) for d in per_image)
+            first = next((d[0][key] for d in per_image if len(d)), None)
+            base = getattr(first, 'base', None)
+            if base is not None and base.shape == (total,) + tail and base.dtype == dtype:
+                return base
+            return np.array([x[key] for d in per_image for x in d], dtype).reshape((-1,) + tail)
+
         def pack_step(dets, feats, poses):
             """The per-frame results of one step as a few arrays (what travels to rank 0; the dicts can be rebuilt there)."""
-            return (np.array([len(d) for d in dets], np.int32),
-                    np.array([x['bbox'] for d in dets for x in d], np.int32).reshape(-1, 4),
-                    np.array([x['landmarks'] for d in dets for x in d], np.int32).reshape(-1, 5, 2),
-                    np.array([x['score'] for d in dets for x in d], np.float32),
+            nd = sum(len(d) for d in dets)
+            return (np.array([len(d) for d in dets], np.int32), rows_of(dets, 'bbox', (4,), np.int32), rows_of(dets, 'landmarks', (5, 2), np.int32),
+                    np.fromiter((x['score'] for d in dets for x in d), np.float32, nd),
                     [np.asarray(f) for f in feats],
                     np.array([len(p) for p in poses], np.int32),
                     np.array([x['keypoints'] for p in poses for x in p], np.int32).reshape(-1, 18, 3),
@@ -767,11 +777,14 @@ def run(args):
                                         batch_size=args.batch, device=device_index) for i in range(R)]
         n_on_rank0 = [0]
         n_messages = [0]
-        G = 8                                                        # steps per gather message
+        # steps per gather message: ONE -- a message is pickled under the GIL (a few hundred KB of result arrays per step: ~0.1 ms);
+        # eight steps per message held the GIL for ~10 ms at a time, most of a step, and the lanes' launch threads waited for it
+        # (world-1 rehearsal: value_ingest 18 % under `value`)
+        G = int(os.environ.get('TA_BENCH_GATHER_STEPS', '1'))
         distlike = None
         if use_dist:
             distlike = dist if gather_group is None else _GroupDist(dist, gather_group)
-        # The ordered gather runs WHILE the region does: a gather thread per rank sends every G finished steps' results to rank 0
+        # The ordered gather runs WHILE the region does: a gather thread per rank sends every G finished steps' results (G = 1) to rank 0
         # (gather_object on the host-side gloo group; every rank runs the same k steps, so every rank issues the same
         # ceil(k / G) collectives in the same order).  What is left for the end of the region is the last message.
         # Without a gloo group beside RCCL the gather stays ONE message at region end (a collective on the default group from
@@ -821,14 +834,23 @@ def run(args):
             t0 = time.perf_counter()
             run_steps(k, readers=readers, on_step=on_step)
             tg = time.perf_counter()
+            t_steps_done = time.time()                   # host wall clock: comparable across the ranks of one node
             gather_all()
             gather_s = time.perf_counter() - tg
+            t_gathered = time.time()
             sync()
             e = time.perf_counter() - t0
             if use_dist:
                 t = torch.tensor([e], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 e = float(t.item())
+                # what the gather costs once the LAST rank has finished its steps (gather_tail_s on rank 0 also contains its wait
+                # for slower ranks, which is not the gather's doing)
+                t = torch.tensor([t_steps_done], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                gather_after_last = max(0.0, t_gathered - float(t.item()))
+            else:
+                gather_after_last = gather_s
         finally:
             for r in readers:
                 r.close()
@@ -837,10 +859,11 @@ def run(args):
             'host_to_device_mb_per_step': round(frames_host.nbytes / 1e6, 1),
             'steps_gathered_on_rank0': n_on_rank0[0],
             'gather_messages': n_messages[0],
-            'gather_tail_s': round(gather_s, 4),           # what the ordered gather still takes once the last step is done (this rank's wait included)
+            'gather_tail_s': round(gather_s, 4),           # rank 0: from ITS last step to the end of the gather (its wait for slower ranks included)
+            'gather_after_last_rank_s': round(gather_after_last, 4),   # from the moment the LAST rank finished its steps to the end of the gather on rank 0
             'what': 'same workload, every batch read from a raw rgb24 byte stream in host memory into pinned buffers and '
                     'uploaded by video.RawVideoReader (one reader thread + upload stream per pipeline, overlapped with '
-                    'compute), the per-step results of all ranks gathered on rank 0 by a gather thread while the region runs (8 steps per message); stream reads are single-thread host memcpys '
+                    'compute), the per-step results of all ranks gathered on rank 0 by a gather thread while the region runs (one message per step); stream reads are single-thread host memcpys '
                     '(a pipe read in the reference, terran/io/video/reader.py:88-117)'}
 
     primary = runtime.resolve_precision(args.precision or os.environ.get('TERRAN_AMD_PRECISION') or HEADLINE)
