@@ -224,19 +224,33 @@ static_assert(RFS_IY * RFS_PITCH % 4 == 0, "tile stays 16-byte aligned");
 struct rf_stem_weights {
   float v[448];                               // passed BY VALUE: wave-uniform reads become scalar loads, FMAs take SGPR operands
 };
-__global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int H, int W, const rf_stem_weights wt,
-                                                       float* out, int Ho, int Wo, int o_img, int o_row, int o_pix, int o_off0) {
+// FUSE (round 6): the NEXT block of the base -- depthwise 3x3 stride 2 (16) + ReLU -> 1x1 (16 -> 32) + ReLU (model.py:26-39,
+// scales.0.0.sep_block + scales.0.1.conv_block) -- runs on the staged tile as well, so the 16-channel half-resolution map (210 MB
+// per 32 frames at 640 x 640, written once and read once) never reaches HBM: the kernel writes the 32-channel QUARTER-resolution
+// map.  A stride-2 output pixel (oy, ox) reads rows 2 oy - 1 .. 2 oy + 1 of the 16-channel map: the 14 x 62 tile starts at the ODD
+// position (2 oy0 - 1, 2 ox0 - 1) and yields 6 x 30 outputs from 13 x 61 of its pixels (tiles step 12 x 60: 1.2 x the front's work
+// for that map).  Pixels of the 16-channel map outside the map are staged as ZEROS (this conv's padding).  5. thread = output pixel:
+// 9 taps x 16 channels from the staging (conflict-free: consecutive pixels are two staged pixels apart), the 1x1 in trips of 4
+// output channels with the weights as scalar loads from `w2` ([9][16] dw, [16] bias, [16][32] 1x1 (c, oc), [32] bias);  6. the 6 x 30
+// x 32 results cross LDS so that a store instruction writes 3.75 KB of consecutive bytes.
+#define RFS_OY 6
+#define RFS_OX 30
+#define RFS_O2ROW (RFS_OX * 8)                // 16-byte chunks per row of the fused output tile
+template <bool FUSE>
+__global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int H, int W, const rf_stem_weights wt, const float* __restrict__ w2,
+                                                       float* out, int Ho, int Wo, int Ho2, int Wo2, int o_img, int o_row, int o_pix, int o_off0) {
   __shared__ __attribute__((aligned(16))) f32x4 lds4[RFS_SLOTS];       // 56 KB: two workgroups per CU
   unsigned* pix = (unsigned*)lds4;
   f32x4* tile = lds4 + RFS_PIX_SLOTS;
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  const int ty0 = blockIdx.y * RFS_TY, tx0 = blockIdx.x * RFS_TX;
+  const int ty0 = FUSE ? 2 * RFS_OY * (int)blockIdx.y - 1 : (int)blockIdx.y * RFS_TY;
+  const int tx0 = FUSE ? 2 * RFS_OX * (int)blockIdx.x - 1 : (int)blockIdx.x * RFS_TX;
   const int iy0 = 2 * (ty0 - 1) - 1, ix0 = 2 * (tx0 - 1) - 1;
   const int Wb = W * 3;
   const uint8_t* imgp = frames + (size_t)img * H * Wb;
-  // misalignment of frame row 0's first window byte, as a non-negative number (ix0 >= -3)
-  const int mis_img = (int)(((size_t)imgp + 12 + ix0 * 3) & 3);
+  // misalignment of frame row 0's first window byte (ix0 >= -5: 24 + 3 ix0 >= 0)
+  const int mis_img = (int)(((size_t)imgp + 24 + ix0 * 3) & 3);
   // 1. window rows as bytes: two rows per pass (waves 0-1 / 2-3), thread = one aligned dword.  All of a thread's loads
   //    are issued before the first one is waited for.  Only tiles on the frame's left / right edge mask bytes.
   const int wb3 = Wb & 3;
@@ -439,15 +453,87 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
   __syncthreads();                                // every tile read is done: window + tile become the output staging
   // 4. staging: row py, chunk (16 bytes) c of thread g at 16 g + (c ^ g)
   if (active) {
+    const bool row_in = !FUSE || (ty0 + py >= 0 && ty0 + py < Ho);
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p) {
+      const int mx = tx0 + 4 * g + p;
+      const bool in_map = row_in && (!FUSE || (mx >= 0 && mx < Wo));       // FUSE: outside the map = the next conv's zero padding
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = p * 4 + q;
-        lds4[py * RFS_OPITCH + 16 * g + (c ^ g)] = r[q][p];
+        lds4[py * RFS_OPITCH + 16 * g + (c ^ g)] = in_map ? r[q][p] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
   }
   __syncthreads();
+  if constexpr (FUSE) {
+    // 5. depthwise 3x3 stride 2 (16) + ReLU -> 1x1 (16 -> 32) + ReLU: thread = output pixel (orow, ocol) of the 6 x 30 tile
+    const int orow = tid / RFS_OX, ocol = tid - orow * RFS_OX;
+    const bool worker = tid < RFS_OY * RFS_OX;
+    f32x4 o8[8];                                  // the pixel's 32 outputs
+    if (worker) {
+      const float* dW = w2;             // [9][16]
+      const float* dB = w2 + 144;
+      const float* pW = w2 + 160;       // [16][32] (c, oc)
+      const float* pB = w2 + 672;
+      float d[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) d[c] = dB[c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int x = 2 * ocol + kx, gx = x >> 2, px = x & 3;
+          const f32x4* src = lds4 + (2 * orow + ky) * RFS_OPITCH + 16 * gx;
+          const float* w = dW + (ky * 3 + kx) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[(4 * px + q) ^ gx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[4 * q + e] = __builtin_fmaf(v[e], w[4 * q + e], d[4 * q + e]);
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) d[c] = fmaxf(d[c], 0.f);
+#pragma nounroll
+      for (int q = 0; q < 8; ++q) {               // output channels 4q .. 4q+3: a real loop, 64 scalar weights per trip
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = pB[4 * q + e];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(d[c], pW[c * 32 + 4 * q + e], a[e]);
+        const f32x4 o4 = {fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
+        if (q == 0) o8[0] = o4;                   // wave-uniform: keeps o8[] in registers without unrolling the loop
+        else if (q == 1) o8[1] = o4;
+        else if (q == 2) o8[2] = o4;
+        else if (q == 3) o8[3] = o4;
+        else if (q == 4) o8[4] = o4;
+        else if (q == 5) o8[5] = o4;
+        else if (q == 6) o8[6] = o4;
+        else o8[7] = o4;
+      }
+    }
+    __syncthreads();                              // every read of the 16-channel staging is done: it becomes the output staging
+    // 6. row orow, pixel ocol, chunk q at 8 ocol + (q ^ (ocol / 2 & 7)): a quarter wave's 16 consecutive pixels hit 16 different banks
+    if (worker) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lds4[orow * RFS_O2ROW + 8 * ocol + (q ^ ((ocol >> 1) & 7))] = o8[q];
+    }
+    __syncthreads();
+    const int oy0 = RFS_OY * (int)blockIdx.y, ox0 = RFS_OX * (int)blockIdx.x;
+    const int oc = tid >> 3;                      // pixel of the row this thread stores a chunk of
+    if (tid < RFS_O2ROW && ox0 + oc < Wo2) {
+      const int q = (tid & 7) ^ ((oc >> 1) & 7);  // the logical chunk that sits at this physical position
+      float* dst = out + (size_t)img * o_img + o_off0 + (size_t)oy0 * o_row + (size_t)(ox0 + oc) * o_pix + q * 4;
+      const int rows = Ho2 - oy0 < RFS_OY ? Ho2 - oy0 : RFS_OY;
+#pragma unroll
+      for (int row = 0; row < RFS_OY; ++row)
+        if (row < rows) *(f32x4*)(dst + (size_t)row * o_row) = lds4[row * RFS_O2ROW + tid];
+    }
+    return;
+  }
   if (tid < RFS_OROW && tx0 + (tid >> 2) < Wo) {          // thread = chunk of a row: constant offsets, one row per trip
     const int gg = tid >> 4;
     const f32x4* src = lds4 + 16 * gg + ((tid & 15) ^ gg);
@@ -459,15 +545,21 @@ __global__ __launch_bounds__(256) void rf_stem_kernel(const uint8_t* frames, int
   }
 }
 
-int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w, const float* weights_host, const ta_tensor& out) {
-  if (!frames_dev || !weights_host || out.c != 16 || out.fmt != TA_FMT_F32 || out.h != (h + 1) / 2 || out.w != (w + 1) / 2 || out.n < n)
+int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w, const float* weights_host, const float* w2_dev, const ta_tensor& out) {
+  // w2_dev: device pointer to the 704 weights of the fused second block (FUSE: `out` is the 32-channel quarter-resolution map), or nullptr
+  const bool fuse = w2_dev != nullptr;
+  const int mh = (h + 1) / 2, mw = (w + 1) / 2;                        // the 16-channel half-resolution map
+  const int oh = fuse ? (mh + 1) / 2 : mh, ow = fuse ? (mw + 1) / 2 : mw;
+  if (!frames_dev || !weights_host || out.c != (fuse ? 32 : 16) || out.fmt != TA_FMT_F32 || out.h != oh || out.w != ow || out.n < n)
     return ta_fail(ctx, TA_E_INVALID, "rfstem: destination tensor mismatch");
   if (n <= 0) return TA_OK;
   if ((uintptr_t)frames_dev & 3)
     return ta_fail(ctx, TA_E_INVALID, "rfstem: the frames must be 4-byte aligned");
-  ta_prof_scope scope(ctx, 0, 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w);   // the two dense convs (depthwise MACs are not counted anywhere)
-  ctx->cur_flops = 2.0 * (216.0 + 128.0) * (double)n * out.h * out.w;
-  ctx->note_kernel("rf_stem_kernel");
+  // the dense convs (depthwise MACs are not counted anywhere)
+  const double flops = 2.0 * (216.0 + 128.0) * (double)n * mh * mw + (fuse ? 2.0 * 512.0 * (double)n * oh * ow : 0.0);
+  ta_prof_scope scope(ctx, 0, flops);
+  ctx->cur_flops = flops;
+  ctx->note_kernel(fuse ? "rf_stem_kernel<true>" : "rf_stem_kernel");
   rf_stem_weights wt;                                                   // 1.8 KB of kernel arguments
   memcpy(wt.v, weights_host, sizeof(wt.v));
   for (int o = 0; o < 8; ++o)                                           // (o, c, ky, kx) -> (ky, kx, c; o)
@@ -475,9 +567,13 @@ int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w
       for (int t = 0; t < 9; ++t) wt.v[(t * 3 + c) * 8 + o] = weights_host[o * 27 + c * 9 + t];
   for (int oc = 0; oc < 16; ++oc)                                       // (oc, c) -> (c, oc)
     for (int c = 0; c < 8; ++c) wt.v[304 + c * 16 + oc] = weights_host[304 + oc * 8 + c];
-  hipLaunchKernelGGL(rf_stem_kernel, dim3((out.w + RFS_TX - 1) / RFS_TX, (out.h + RFS_TY - 1) / RFS_TY, n), dim3(256), 0, ctx->stream,
-                     frames_dev, h, w, wt, out.dev, out.h, out.w, (int)((size_t)out.hp() * out.wp() * out.c), out.wp() * out.c,
-                     out.c, (int)out.off(0, 0, 0));
+  const int o_img = (int)((size_t)out.hp() * out.wp() * out.c), o_row = out.wp() * out.c, o_off0 = (int)out.off(0, 0, 0);
+  if (fuse)
+    hipLaunchKernelGGL(rf_stem_kernel<true>, dim3((ow + RFS_OX - 1) / RFS_OX, (oh + RFS_OY - 1) / RFS_OY, n), dim3(256), 0, ctx->stream,
+                       frames_dev, h, w, wt, w2_dev, out.dev, mh, mw, oh, ow, o_img, o_row, out.c, o_off0);
+  else
+    hipLaunchKernelGGL(rf_stem_kernel<false>, dim3((mw + RFS_TX - 1) / RFS_TX, (mh + RFS_TY - 1) / RFS_TY, n), dim3(256), 0, ctx->stream,
+                       frames_dev, h, w, wt, (const float*)nullptr, out.dev, mh, mw, mh, mw, o_img, o_row, out.c, o_off0);
   TA_HIP(ctx, hipGetLastError());
   return TA_OK;
 }

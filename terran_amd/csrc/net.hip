@@ -184,7 +184,10 @@ int ta_model_plan(ta_model* m, int n_run, int h, int w) {
       case TA_OP_RFSTEM:
         if (oi != 0 || op.in != in_id || m->tdesc[op.in].alias_of != -2 || op.w_off < 0)
           return ta_fail(ctx, TA_E_INVALID, "plan: the RetinaFace front op must be op 0 on a shape-only input tensor");
-        TA_TRY(set_out(op.out, (ti.h + 1) / 2, (ti.w + 1) / 2));
+        if (op.cout == 32)                           // fused with the next block (dw3x3 s2 -> 1x1 16 -> 32): quarter resolution
+          TA_TRY(set_out(op.out, ((ti.h + 1) / 2 + 1) / 2, ((ti.w + 1) / 2 + 1) / 2));
+        else
+          TA_TRY(set_out(op.out, (ti.h + 1) / 2, (ti.w + 1) / 2));
         break;
       case TA_OP_DWPW:
         if (ti.halo < 1) return ta_fail(ctx, TA_E_INVALID, "plan: op %zu (dw+pw) needs an input halo", oi);
@@ -443,7 +446,8 @@ int ta_model_run_ops(ta_model* m) {
         break;
       }
       case TA_OP_RFSTEM:
-        TA_TRY(ta_launch_rfstem(ctx, m->input_u8, m->run_n, ti.h, ti.w, (const float*)m->weights_host_small.data(), to));
+        TA_TRY(ta_launch_rfstem(ctx, m->input_u8, m->run_n, ti.h, ti.w, (const float*)m->weights_host_small.data(),
+                                op.cout == 32 ? wptr(m, op.w_off) + 448 : nullptr, to));
         break;
       case TA_OP_DWPW: {
         ta_conv_launch p;
@@ -528,7 +532,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
   if (bytes < sizeof(ta_blob_header)) return ta_fail(ctx, TA_E_INVALID, "model blob too small");
   ta_blob_header h;
   memcpy(&h, blob, sizeof(h));
-  if (h.magic != TA_BLOB_MAGIC || h.version != 8) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version (this library reads version 8)");
+  if (h.magic != TA_BLOB_MAGIC || h.version != 9) return ta_fail(ctx, TA_E_INVALID, "model blob: bad magic/version (this library reads version 9)");
   if (h.kind != kind) return ta_fail(ctx, TA_E_INVALID, "model blob is kind %d, expected %d", h.kind, kind);
   if (h.n_tensors <= 0 || h.n_ops <= 0 || h.n_outputs < 0 || h.n_outputs > 16 || h.input_tensor < 0 ||
       h.input_tensor >= h.n_tensors)
@@ -558,7 +562,7 @@ int ta_model_load(ta_ctx* ctx, int kind, const void* blob, size_t bytes, ta_mode
             (((op.variant >> 16) & 1) && (op.out2 >= 0 || op.scale2_off < 0 || op.kh != 3 || op.kw != 3 || op.stride != 1 || op.pad != 1 ||
                                           op.pool || bad_w(op.scale2_off, (size_t)16 * op.coutp * 4)));
     } else if (op.type == TA_OP_RFSTEM) {
-      bad = bad || op.w_off < 0 || bad_w(op.w_off, 448 * 4);
+      bad = bad || op.w_off < 0 || (op.cout != 16 && op.cout != 32) || bad_w(op.w_off, (op.cout == 32 ? 448 + 704 : 448) * 4);
     } else if (op.type == TA_OP_DWPW) {
       bad = bad || op.w_off < 0 || op.bias_off < 0 || op.scale2_off < 0 || op.shift2_off < 0 || op.cin % 4 || op.cout % 4 ||
             (op.prec != 0 && op.prec != 3) || op.wus_off != op.bias_off + 4 * (int64_t)op.coutp || bad_w(op.wus_off, (size_t)op.coutp * 4) ||

@@ -22,7 +22,7 @@ enum {
   TA_OP_DWCONV = 2,
   TA_OP_MAXPOOL = 3,
   TA_OP_COPYCH = 4,
-  TA_OP_RFSTEM = 5,   // RetinaFace front: uint8 frames -> conv3x3 s2 (3 -> 8) -> dw3x3 (8) -> 1x1 (8 -> 16), all + BN + ReLU, one kernel
+  TA_OP_RFSTEM = 5,   // RetinaFace front: uint8 frames -> conv3x3 s2 (3 -> 8) -> dw3x3 (8) -> 1x1 (8 -> 16), all + BN + ReLU, one kernel; cout == 32: + the next block (dw3x3 s2 (16) -> 1x1 (16 -> 32)) in the same kernel
   TA_OP_DWPW = 6      // depthwise 3x3 (stride 1 / 2) + BN + ReLU fused into the following 1x1 conv + BN + ReLU (exact-f32 MFMA)
 };
 enum { TA_ACT_NONE = 0, TA_ACT_RELU = 1, TA_ACT_PRELU = 2 };
@@ -333,7 +333,7 @@ int ta_launch_conv(ta_ctx* ctx, const ta_conv_launch& p, double flops);
 int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p, double flops);
 struct ta_frames;
 // RetinaFace front kernel: frames (uint8 RGB) -> 16-channel float tensor at half resolution; 448 packed floats in HOST memory
-int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w, const float* weights_host, const struct ta_tensor& out);
+int ta_launch_rfstem(ta_ctx* ctx, const uint8_t* frames_dev, int n, int h, int w, const float* weights_host, const float* w2_dev, const struct ta_tensor& out);
 
 struct ta_dw_launch {
   const float* in;

@@ -37,13 +37,13 @@ _OP_I32 = ['type', 'in', 'out', 'in_ch_off', 'cin', 'out_ch_off', 'cout', 'coutp
 _OP_I64 = ['w_off', 'bias_off', 'prelu_off', 'scale2_off', 'shift2_off', 'wus_off']
 OP_DT = np.dtype([(n, '<i4') for n in _OP_I32] + [(n, '<i8') for n in _OP_I64] + [('macs_per_pixel', '<f8')])
 assert OP_DT.itemsize == 152 and TENSOR_DT.itemsize == 20
-BLOB_VERSION = 8            # 8: per-channel activation scales (ta_tensor_desc.unscale_off) and per-output-channel un-scale vectors (ta_op_desc.wus_off) replace the per-layer wscale_log2; 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
+BLOB_VERSION = 9            # 9: OP_RFSTEM with cout == 32 = the front kernel fused with the next depthwise + 1x1 block; 8: per-channel activation scales (ta_tensor_desc.unscale_off) and per-output-channel un-scale vectors (ta_op_desc.wus_off) replace the per-layer wscale_log2; 7: arithmetic mode 4 ('f16') and the 2-byte tensor format; 6: op lanes (variant bits 17..18); 2: ta_op_desc grew `groups` (grouped convs); 3: fused RetinaFace ops (OP_RFSTEM, OP_DWPW), `variant`; 4: `pool`; 5: `wscale_log2` (f16x3)
 
 
 # every environment switch a packer reads: a program packed with one of them set must never be served to a default run
 # (runtime.packed_program bypasses the on-disk repack cache then, and keys its in-process memo on them)
 PACK_SWITCHES = ('TERRAN_AMD_NO_FUSED_POOL', 'TERRAN_AMD_NO_GROUPED', 'TERRAN_AMD_NO_MERGED_OUTPUTS', 'TERRAN_AMD_ARCFACE_SECOND_OUTPUT',
-                 'TERRAN_AMD_NO_STAGE4_KSPLIT', 'TERRAN_AMD_DETECTOR_F32', 'TERRAN_AMD_DETECTOR_BASE_F32', 'TERRAN_AMD_NO_FUSED_DETECTOR',
+                 'TERRAN_AMD_NO_STAGE4_KSPLIT', 'TERRAN_AMD_DETECTOR_F32', 'TERRAN_AMD_DETECTOR_BASE_F32', 'TERRAN_AMD_NO_FUSED_DETECTOR', 'TERRAN_AMD_NO_FUSED_FRONT',
                  'TERRAN_AMD_NO_DETECTOR_LANES', 'TERRAN_AMD_NO_ACT_SCALES')
 
 
@@ -456,18 +456,25 @@ class Program:
         return (np.asarray(bias, np.float64) + mu_in * wsum,
                 var_in * ((1.0 - _TAP_CORR) * wsq + _TAP_CORR * wsum * wsum))
 
-    def rfstem(self, tin, tout, Ws, bs, Wd, bd, Wp, bp):
+    def rfstem(self, tin, tout, Ws, bs, Wd, bd, Wp, bp, Wd2=None, bd2=None, Wp2=None, bp2=None):
         """RetinaFace front as ONE op: conv3x3 s2 (3 -> 8) -> depthwise 3x3 (8) -> 1x1 (8 -> 16), each + folded BN + ReLU.
-        Ws (8,3,3,3) / bs (8,), Wd (8,1,3,3) / bd (8,), Wp (16,8,1,1) / bp (16,), all already folded."""
+        Ws (8,3,3,3) / bs (8,), Wd (8,1,3,3) / bd (8,), Wp (16,8,1,1) / bp (16,), all already folded.
+        With Wd2 (16,1,3,3) / bd2 (16,), Wp2 (32,16,1,1) / bp2 (32,): the NEXT block of the base -- depthwise 3x3 stride 2 (16) ->
+        1x1 (16 -> 32), retinaface/model.py:26-39 -- in the same kernel: `tout` is the 32-channel quarter-resolution map and
+        the 16-channel half-resolution map (the largest tensor of the network) never reaches HBM."""
         parts = [np.asarray(Ws, np.float64).reshape(8, 27).ravel(), np.asarray(bs, np.float64),
                  np.asarray(Wd, np.float64).reshape(8, 9).T.ravel(), np.asarray(bd, np.float64),
                  np.asarray(Wp, np.float64).reshape(16, 8).ravel(), np.asarray(bp, np.float64)]
+        fuse = Wd2 is not None
+        if fuse:                        # [9][16] depthwise taps, [16] bias, [16][32] 1x1 as (c, oc), [32] bias: what rf_stem_kernel<true> reads
+            parts += [np.asarray(Wd2, np.float64).reshape(16, 9).T.ravel(), np.asarray(bd2, np.float64),
+                      np.asarray(Wp2, np.float64).reshape(32, 16).T.ravel(), np.asarray(bp2, np.float64)]
         blob = np.concatenate(parts)
-        assert blob.size == 448
-        op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=16, coutp=32, kh=3, kw=3, stride=2,
+        assert blob.size == (448 + 704 if fuse else 448)
+        op = dict(type=OP_RFSTEM, out=tout, in_ch_off=0, cin=4, out_ch_off=0, cout=32 if fuse else 16, coutp=32, kh=3, kw=3, stride=2,
                   pad=1, act=ACT_RELU, res=-1, res_ch_off=0, res_up2=0, out2=-1, out2_ch_off=0, n_slabs=0, prec=0, groups=1,
                   variant=0, pool=0, wscale_log2=0, w_off=self._w(blob), bias_off=-1, prelu_off=-1, scale2_off=-1, shift2_off=-1,
-                  wus_off=-1, macs_per_pixel=float(8 * 27 + 16 * 8))
+                  wus_off=-1, macs_per_pixel=float(8 * 27 + 16 * 8) + (32 * 16 / 4.0 if fuse else 0.0))
         op['in'] = tin
         self._fold[len(self.ops)] = dict(rfstem=parts)
         self.ops.append(op)
@@ -482,6 +489,12 @@ class Program:
         mu, var = act_moments(mu, var, ACT_RELU)
         wp = np.asarray(Wp, np.float64).reshape(16, 8)
         mu, var = np.asarray(bp, np.float64) + wp @ mu, (wp * wp) @ var
+        if fuse:
+            mu, var = act_moments(mu, var, ACT_RELU)
+            mu, var = self._dw_moments(np.asarray(Wd2, np.float64).reshape(16, 9).T, bd2, mu, var)
+            mu, var = act_moments(mu, var, ACT_RELU)
+            wp2 = np.asarray(Wp2, np.float64).reshape(32, 16)
+            mu, var = np.asarray(bp2, np.float64) + wp2 @ mu, (wp2 * wp2) @ var
         self._write_stats(tout, 0, *act_moments(mu, var, ACT_RELU), self._act_bound(mu, var, ACT_RELU))
 
     def dwpw(self, tin, tout, Wd, bd, Wp, bp, *, stride=1, precision=None):
@@ -801,8 +814,12 @@ class Program:
                 self._rewrite(op['bias_off'], np.concatenate([f['bias'] * up, np.ldexp(np.ones(op['coutp']), (a_out - wexp).astype(np.int32))]))
             elif op['type'] == OP_RFSTEM:
                 parts = list(f['rfstem'])
-                parts[4] = (parts[4].reshape(16, 8) * up[:16, None]).ravel()
-                parts[5] = parts[5] * up[:16]
+                if len(parts) == 10:        # fused second block: the stored tensor is ITS output; the 16-channel map stays inside the kernel
+                    parts[8] = (parts[8].reshape(16, 32) * up[None, :32]).ravel()
+                    parts[9] = parts[9] * up[:32]
+                else:
+                    parts[4] = (parts[4].reshape(16, 8) * up[:16, None]).ravel()
+                    parts[5] = parts[5] * up[:16]
                 self._rewrite(op['w_off'], np.concatenate(parts))
         ops = np.zeros(len(self.ops), OP_DT)
         for i, op in enumerate(self.ops):
@@ -1090,12 +1107,22 @@ def pack_retinaface(sd, precision='f32', fused=None):
     if fused:
         Ws, bs = cbr('base.first_conv_block.0', 'base.first_conv_block.1')
         t = None
+        # the front kernel also runs the next block (depthwise stride 2 -> 1x1 16 -> 32): the 16-channel half-resolution map stays
+        # on the CU (TERRAN_AMD_NO_FUSED_FRONT: the two as separate launches, A/B)
+        fuse_front = not os.environ.get('TERRAN_AMD_NO_FUSED_FRONT')
+        front = None
         for i, ((dk, dbn, stride), (pk, pbn, cout, both)) in enumerate(zip(dw_keys, pw_keys)):
             Wd, bd = cbr(dk, dbn)
             Wp, bp = cbr(pk, pbn)
+            if i == 0 and fuse_front:
+                front = (Wd, bd, Wp, bp)
+                continue
             c = P.tensor(cout, 1 if i < 12 else 0)
             if i == 0:
                 P.rfstem(tin, c, Ws, bs, Wd, bd, Wp, bp)
+            elif i == 1 and front is not None:
+                assert stride == 2 and cout == 32 and Wd.shape[0] == 16 and not both
+                P.rfstem(tin, c, Ws, bs, *front, Wd, bd, Wp, bp)
             else:
                 # the 1x1 of a [depthwise -> pointwise] block follows the refiner's mode from the stride-8 maps on (cin >= 64):
                 # the two blocks on the 104 x 185 maps are bound by their depthwise taps and stay exact f32

@@ -121,7 +121,10 @@ def test_pack_programs_are_well_formed(states):
                     oh, ow = oh // 2, ow // 2
             elif op['type'] == pack.OP_RFSTEM:                     # conv3x3 s2 + depthwise (8 ch) + 1x1, one op
                 oh, ow = (ih + 1) // 2, (iw + 1) // 2
-                total += (op['macs_per_pixel'] + 72) * oh * ow
+                total += (8 * 27 + 16 * 8 + 72) * oh * ow
+                if op['cout'] == 32:                                # ... fused with the next block: depthwise s2 (16 ch) + 1x1 16 -> 32
+                    oh, ow = (oh + 1) // 2, (ow + 1) // 2
+                    total += (32 * 16 + 144) * oh * ow
             elif op['type'] == pack.OP_DWPW:                       # depthwise 3x3 (stride) + 1x1, one op
                 oh, ow = (ih - 1) // op['stride'] + 1, (iw - 1) // op['stride'] + 1
                 total += (op['macs_per_pixel'] + 9 * op['cin']) * oh * ow
