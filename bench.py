@@ -772,7 +772,9 @@ def run(args):
                     np.array([x['keypoints'] for p in poses for x in p], np.int32).reshape(-1, 18, 3),
                     np.array([x['score'] for p in poses for x in p], np.float64))
 
-        R = L                                                        # reader threads (pinned double buffers + upload stream each; a stream read is a single-thread ~30 ms memcpy)
+        # reader threads (pinned double buffers + upload stream each): a stream read is a single-thread memcpy of the 199 MB batch, 25 - 40 ms
+        # depending on the box, against a 14 ms step: four readers whatever the number of lanes (two read 1 390 frames/s on a slow box)
+        R = max(L, 4)
         readers = [video.RawVideoReader(LoopStream(frames_host, len(range(i, k + 2 * L, R))), W, H,
                                         batch_size=args.batch, device=device_index) for i in range(R)]
         n_on_rank0 = [0]

@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/collect
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python $R/bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O/bench.err
 SER="--steps 3 --warmup 1 --serial --no-cpu-baseline --single-mode"
-for P in f16x2 f16x3 f32; do
+for P in f16x3 f16x2 f32; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_$P -o k -- python $R/bench.py $SER --precision $P > $O/kt_$P.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES; do
     timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${C}_$P -o c -- python $R/bench.py --steps 1 --warmup 1 --serial --no-cpu-baseline --single-mode --precision $P > $O/pmc_${C}_$P.log 2>&1
