@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256, (STAGES * (WAVES_M * WM_TILES + WAVES_N * WN_T
 // chain in (ky, kx) order exactly like dwconv3x3_kernel -- instead of DMA'd.  The 1x1 runs on the exact-f32 MFMA, or
 // (PREC_F16X3: pack.dwpw(precision='f16x3')) on the split-half MFMA with the float32 depthwise rows split in registers.
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC = PREC_F32>
-__global__ __launch_bounds__(256, (WAVES_N * WN_TILES == 1 ? 4 : (WAVES_N * WN_TILES == 2 ? 3 : 2))) void conv_dwpw(const ta_conv_launch p) {
+__global__ __launch_bounds__(256, 2) void conv_dwpw(const ta_conv_launch p) {
   // Measured alternatives (32 x 416 x 739 frames, 12 blocks): this symmetric 4-wave kernel, two workgroups per CU,
   // 541 us; 8 waves with the tap loads of slab s+1 issued ahead of the MFMAs of slab s (208 VGPRs, one workgroup per CU,
   // 306 tiles -> two rounds) 631 us.
@@ -2216,6 +2216,300 @@ static int launch_pipe(ta_ctx* ctx, const ta_conv_launch& p) {
   return TA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rf_dwpw_kernel (round 6): the SAME [depthwise 3x3 -> 1x1] block as conv_dwpw above, written for the one shape of work the
+// detector's deep base has -- split-half (f16x3) 1x1, input channels a multiple of 32, output channels a multiple of 8, bias +
+// ReLU epilogue -- instead of instantiated from the generic tile machinery.  conv_dwpw spends ~15 M wave-instructions on a
+// 40 x 40 x 128 block whose arithmetic needs ~1.4 M (profiles/r06_dwpw_*): run-time epilogue flags, 64-bit addressing, the
+// pixel operand re-converted by every wave that consumes it, ten global loads of depthwise weights per slab.  Here:
+//   * taps are buffer loads: one 32-bit byte offset per pixel row, tap and slab offsets in the scalar offset -- no vector address math;
+//   * the depthwise weights of ALL channels sit in LDS ([9 taps + bias][C]), loaded once per workgroup;
+//   * a row is split into half floats ONCE, by the thread that computed it, and stored as the [hi x32 | lo x32] image the weight
+//     rows already have: every consumer wave reads ready fragments (ds_read_b128), no VALU between LDS and MFMA;
+//   * the drain's bias / un-scale vectors are loaded before the K loop; the drain is fma + max + store with 32-bit offsets.
+// Same products in the same order as conv_dwpw (al*bh, ah*bl, ah*bh per k-step; bias + fmaf chain in (ky, kx) order; fmaf(acc, us,
+// bias) in the drain): a block's output bits do not depend on which of the two kernels ran it (tests pin both).
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__global__ __launch_bounds__(256, 2) void rf_dwpw_kernel(const ta_conv_launch p) {
+  constexpr int BN = WAVES_M * WM_TILES * 32, BM = WAVES_N * WN_TILES * 32;
+  constexpr int QA = BN / 32, RP = BM / 32, STAGE = (BN + BM) * 32;
+  static_assert(WAVES_M * WAVES_N == 4 && (RP == 2 || RP == 4), "4 waves; 64 or 128 pixels per tile");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int n_ct = p.coutp / BN;
+  const int bid = blockIdx.x;
+  const int grp = bid >> 3, xcd = bid & 7;
+  const int ct = grp % n_ct;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int pt = ta_xcd_tile(n_pt, xcd, grp / n_ct);
+  if (pt < 0) return;
+  const int ct0 = ct * BN, pt0 = pt * BM;
+  const int HoWo = p.Ho * p.Wo;
+  const int C = p.dw_c, S = p.n_slabs;
+
+  // drain constants of this lane's 8 output channels, and the depthwise weight table: issued first
+  f32x4 pre[4];                                      // bias (2 x 4 channels), un-scale (2 x 4): both padded to coutp
+  {
+    const int pco = ct0 + 8 * (tid % (BN / 8));
+    pre[0] = *(const f32x4*)(p.bias + pco);
+    pre[1] = *(const f32x4*)(p.bias + pco + 4);
+    pre[2] = *(const f32x4*)(p.bias + p.coutp + pco);
+    pre[3] = *(const f32x4*)(p.bias + p.coutp + pco + 4);
+  }
+  float* wl = lds + 2 * STAGE;                       // [10][C]
+  const int n_gran = 10 * C / 4;
+  constexpr int WG = 3;
+  f32x4 wtmp[WG];
+#pragma unroll
+  for (int i = 0; i < WG; ++i) {
+    const int g = tid + 256 * i;
+    wtmp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g < n_gran) wtmp[i] = g * 4 < 9 * C ? *(const f32x4*)(p.dw_w + g * 4) : *(const f32x4*)(p.dw_bias + (g * 4 - 9 * C));
+  }
+
+  // weight rows of a slab: LDS DMA as in conv_dwpw
+  const int pchunk = lane & 7;
+  const int lchunk = pchunk ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const char* a_src[QA];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int row = (q * 4 + wave) * 8 + (lane >> 3);
+    a_src[q] = (const char*)(p.w + ((size_t)(ct0 + row)) * 32 + lchunk * 4);
+  }
+  const size_t a_slab_bytes = (size_t)p.coutp * 128;
+  auto dma_w = [&](int s, int stage) {
+    float* base = lds + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int t = q * 4 + wave;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + (size_t)s * a_slab_bytes), LDS_PTR(base + t * 256), 16, 0, 0);
+    }
+  };
+
+  // pixel rows: thread -> 4 channels c4 of the slab, rows (tid >> 3) + 32 j; a row's taps are one byte offset + scalar offsets
+  const int c4 = tid & 7;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, -1, 0x00020000);
+  int voff[RP];
+#pragma unroll
+  for (int j = 0; j < RP; ++j) {
+    const int row = (tid >> 3) + 32 * j;
+    int pix = pt0 + row;
+    if (pix >= p.M) pix = 0;                        // clamp: the store is masked
+    const int img = pix / HoWo;
+    const int rem = pix - img * HoWo;
+    const int y = rem / p.Wo;
+    const int x = rem - y * p.Wo;
+    voff[j] = 4 * (img * p.in_img + y * p.dw_stride * p.in_row + x * p.dw_stride * p.in_pix + p.in_off0) + 16 * c4;
+  }
+  const int row_b = 4 * p.in_row, pix_b = 4 * p.in_pix;
+
+  unsigned dw_amax = 0;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // depthwise rows of slab s (two pixel rows of this thread at a time: 18 loads in flight), split, into the stage
+  auto produce = [&](int s, int stage) {
+    float* base = lds + stage * STAGE;
+    const int ch = s * 32 + c4 * 4;
+    f32x4 w9[9], bias;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w9[t] = *(const f32x4*)(wl + t * C + ch);
+    bias = *(const f32x4*)(wl + 9 * C + ch);
+#pragma unroll
+    for (int j0 = 0; j0 < RP; j0 += 2) {
+      f32x4 v[2][9];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#ifdef TA_CONV_TRACE      // debug build only (TA_DWPW_PROBE bit 0: no tap loads; timing ablation, WRONG results)
+            v[jj][ky * 3 + kx] = (p.probe & 1) ? f32x4{1.f, 1.f, 1.f, 1.f} : __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j0 + jj], ky * row_b + kx * pix_b + s * 128, 0));
+#else
+            v[jj][ky * 3 + kx] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j0 + jj], ky * row_b + kx * pix_b + s * 128, 0));
+#endif
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int row = (tid >> 3) + 32 * (j0 + jj);
+        f32x4 acc = bias;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v[jj][t][e], w9[t][e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = ta_relu(acc[e]);
+        dw_amax = ta_amax4(dw_amax, acc);            // these rows are split into half floats: range-checked like a stored tensor
+        unsigned h0, h1, l0, l1;
+        ta_pack2<true>(acc[0], acc[1], h0, l0);
+        ta_pack2<true>(acc[2], acc[3], h1, l1);
+        const int sw = (row >> 1) & 7;
+        float* r = base + (BN + row) * 32 + (c4 & 1) * 2;
+        *(uint2*)(r + (((c4 >> 1)) ^ sw) * 4) = make_uint2(h0, h1);
+        *(uint2*)(r + ((4 + (c4 >> 1)) ^ sw) * 4) = make_uint2(l0, l1);
+      }
+    }
+  };
+
+  f32x16 acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+    for (int b = 0; b < WN_TILES; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int kg = lane >> 5;
+  const int a_row0 = wm * WM_TILES * 32 + frow;
+  const int b_row0 = BN + wn * WN_TILES * 32 + frow;
+  auto mma = [&](int s) {
+    const float* st = lds + (s & 1) * STAGE;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a) {
+        ah[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+        al[a] = *(const bf16x8*)(st + (a_row0 + a * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      }
+#pragma unroll
+      for (int b = 0; b < WN_TILES; ++b) {
+        bh[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((2 * kg + t) ^ fsw) * 4);
+        bl[b] = *(const bf16x8*)(st + (b_row0 + b * 32) * 32 + ((4 + 2 * kg + t) ^ fsw) * 4);
+      }
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) acc[a][b] = ta_mfma16<PREC_F16X3>(al[a], bh[b], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) acc[a][b] = ta_mfma16<PREC_F16X3>(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+        for (int b = 0; b < WN_TILES; ++b) acc[a][b] = ta_mfma16<PREC_F16X3>(ah[a], bh[b], acc[a][b]);
+    }
+  };
+
+  dma_w(0, 0);
+#pragma unroll
+  for (int i = 0; i < WG; ++i)
+    if (tid + 256 * i < n_gran) *(f32x4*)(wl + (tid + 256 * i) * 4) = wtmp[i];
+  for (int g = tid + 256 * WG; g < n_gran; g += 256)   // (more than 768 granules: 300+ input channels)
+    *(f32x4*)(wl + g * 4) = g * 4 < 9 * C ? *(const f32x4*)(p.dw_w + g * 4) : *(const f32x4*)(p.dw_bias + (g * 4 - 9 * C));
+  __syncthreads();                                   // the weight table is complete
+  produce(0, 0);
+  for (int s = 0; s < S; ++s) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                 // slab s complete (weights landed, rows written); the other stage is free
+    if (s + 1 < S) {
+#ifdef TA_CONV_TRACE      // debug build only (TA_DWPW_PROBE bit 2: weight rows DMA'd for slab 0 only; bit 3: no MFMAs)
+      if (!(p.probe & 4))
+#endif
+      dma_w(s + 1, (s + 1) & 1);
+      produce(s + 1, (s + 1) & 1);
+    }
+#ifdef TA_CONV_TRACE
+    if (!(p.probe & 8))
+#endif
+    mma(s);
+  }
+  if (dw_amax > TA_F16_MAX_BITS) *p.range_flag = 1;
+  if (p.amax_index >= 0 && dw_amax) atomicMax((unsigned*)p.range_flag + TA_AMAX_SLOT0 + 2 * p.amax_index + 1, dw_amax);
+
+  // ---- epilogue: park the raw tile [pixel][cout] in the ring, drain one lane per (pixel, 8 channels) ----------------------
+  constexpr int NCH = BN / 4, G = BN / 8, RPI = 256 / G;
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < WN_TILES; ++b) {
+    const int row = (wn * WN_TILES + b) * 32 + (lane & 31);
+#pragma unroll
+    for (int a = 0; a < WM_TILES; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = ((wm * WM_TILES + a) * 32 + 8 * j + 4 * (lane >> 5)) >> 2;
+        *(f32x4*)(lds + (row * NCH + (c ^ (row & (NCH - 1)))) * 4) =
+            f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+      }
+  }
+  __syncthreads();
+  const int k8 = tid % G, r0 = tid / G;
+  const int co = ct0 + 8 * k8;
+  unsigned amax = 0;
+  if (co < p.cout) {                                 // cout % 8 == 0: a lane is inside or outside with all 8 channels
+    const bool split = p.out_fmt == TA_FMT_SPLIT16;  // uniform
+    const bool chk = p.range_check != 0;
+    char* const ob = (char*)p.out + (split ? ta_split_chan(p.out_ch + co) : 4u * (unsigned)(p.out_ch + co));
+    int pix = pt0 + r0;
+    int img = pix / HoWo;
+    int rem = pix - img * HoWo;
+    int y = rem / p.Wo;
+    int x = rem - y * p.Wo;
+    for (int row = r0; row < BM; row += RPI, pix += RPI) {
+      if (pix >= p.M) break;
+      const int sw = row & (NCH - 1);
+      float v[8];
+      *(f32x4*)v = *(const f32x4*)(lds + (row * NCH + ((2 * k8) ^ sw)) * 4);
+      *(f32x4*)(v + 4) = *(const f32x4*)(lds + (row * NCH + ((2 * k8 + 1) ^ sw)) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = ta_relu(__builtin_fmaf(v[e], pre[2][e], pre[0][e]));
+        v[4 + e] = ta_relu(__builtin_fmaf(v[4 + e], pre[3][e], pre[1][e]));
+      }
+      char* o = ob + 4u * (unsigned)(img * p.out_img + y * p.out_row + x * p.out_pix + p.out_off0);
+#ifdef TA_CONV_TRACE      // debug build only (TA_DWPW_PROBE bit 1: no output stores)
+      if ((p.probe & 2) && v[0] != 12345.f) {
+        amax = max(amax, ta_absbits(v[0]));
+        continue;
+      }
+#endif
+      if (split) {
+        unsigned am = 0;
+        ta_split_store8<1>(o, v, am);
+        amax = max(amax, am);
+      } else {
+        *(f32x4*)o = *(const f32x4*)v;
+        *(f32x4*)(o + 16) = *(const f32x4*)(v + 4);
+        if (chk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) amax = max(amax, ta_absbits(v[e]));
+        }
+      }
+      x += RPI;                                      // next pass: RPI pixels further in raster order
+      while (x >= p.Wo) {
+        x -= p.Wo;
+        if (++y == p.Ho) {
+          y = 0;
+          ++img;
+        }
+      }
+    }
+  }
+  ta_range_report(p, amax);
+}
+
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+static int launch_rf_dwpw(ta_ctx* ctx, const ta_conv_launch& p) {
+  constexpr int BN = WAVES_M * WM_TILES * 32, BM = WAVES_N * WN_TILES * 32;
+  const int n_ct = p.coutp / BN;
+  const int n_pt = (p.M + BM - 1) / BM;
+  const int groups = ((n_pt + 7) / 8) * n_ct;
+  const size_t lds_bytes = 2 * (size_t)(BN + BM) * 32 * sizeof(float) + (size_t)40 * p.dw_c;   // two stages + the depthwise weight table [10][C]
+  auto kern = rf_dwpw_kernel<WAVES_M, WAVES_N, WM_TILES, WN_TILES>;
+  {
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "rf_dwpw_kernel<%d,%d,%d,%d>", WAVES_M, WAVES_N, WM_TILES, WN_TILES);
+    ctx->note_kernel(name);
+  }
+  TA_SET_LDS_ATTR(ctx, kern, lds_bytes);
+  hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), lds_bytes, ctx->stream, p);
+  TA_HIP(ctx, hipGetLastError());
+  return TA_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int PREC>
 static int launch_dwpw_cfg(ta_ctx* ctx, const ta_conv_launch& p) {
   constexpr int BN = WAVES_M * WM_TILES * 32;
@@ -2246,36 +2540,24 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
   ta_prof_scope scope(ctx, 0, flops);
   ctx->cur_flops = flops;
 #ifdef TA_CONV_TRACE
-  static const int dw_probe = getenv("TA_DWPW_PROBE") ? atoi(getenv("TA_DWPW_PROBE")) & 3 : 0;   // debug build: timing ablations
+  static const int dw_probe = getenv("TA_DWPW_PROBE") ? atoi(getenv("TA_DWPW_PROBE")) & 15 : 0;   // debug build: timing ablations (conv_dwpw reads bits 0..1 as a number, rf_dwpw_kernel bits 0..3 as flags)
   p.probe = dw_probe;
 #endif
-  // Pixels per tile.  A block's time is ONE tile's chain (produce a slab's depthwise rows -> barrier -> MFMAs, per 32 input
-  // channels; then park and drain): on the 40 x 40 and 20 x 20 maps a 128-pixel tile gives 400 / 100 workgroups for 256 CUs,
-  // each walking 4 - 8 slabs with four pixel rows per thread.  Smaller pixel tiles shorten the chain (fewer rows per thread per
-  // slab, fewer MFMAs per wave) and put 3 - 4 workgroups on a CU to hide each other's load latencies; what they cost is the
-  // weight slab, re-read from L2 once per tile.  Same MFMA K order per output element: a layer's bits do not depend on the tile.
-  // TA_DWPW_BM = 128 / 64 / 32 pins the choice (tools).
-  static const int bm_force = getenv("TA_DWPW_BM") ? atoi(getenv("TA_DWPW_BM")) : 0;
-  int bm = 128;
-  if (p.coutp % 128 == 0) {
-    const int tiles128 = (p.M + 127) / 128 * (p.coutp / 128);
-    bm = tiles128 >= 1024 ? 128 : (tiles128 >= 256 ? 64 : 32);
-    if (bm_force == 128 || bm_force == 64 || bm_force == 32) bm = bm_force;
-  }
   if (p.prec == PREC_F16X3) {
-    if (p.coutp % 128 == 0) {
-      if (bm == 32) return launch_dwpw_cfg<4, 1, 1, 1, PREC_F16X3>(ctx, p);
-      if (bm == 64) return launch_dwpw_cfg<2, 2, 2, 1, PREC_F16X3>(ctx, p);
-      return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
+    // the lean kernel wherever the block has the shape it is written for (every f16x3 block of the detector's base); TA_DWPW_GENERIC: A/B
+    static const bool generic_only = getenv("TA_DWPW_GENERIC") != nullptr;
+    const bool lean_ok = !generic_only && p.dw_c % 32 == 0 && p.dw_c == p.n_slabs * 32 && p.dw_c <= 1024 && p.cout % 8 == 0 && p.act == TA_ACT_RELU &&
+                         (p.out_fmt == TA_FMT_F32 || p.out_fmt == TA_FMT_SPLIT16);
+    if (lean_ok) {
+      if (p.coutp % 128 == 0) return launch_rf_dwpw<2, 2, 2, 1>(ctx, p);
+      if (p.coutp % 64 == 0) return launch_rf_dwpw<2, 2, 1, 1>(ctx, p);
+      return launch_rf_dwpw<1, 4, 1, 1>(ctx, p);
     }
+    if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F16X3>(ctx, p);
     if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F16X3>(ctx, p);
     return launch_dwpw_cfg<1, 4, 1, 1, PREC_F16X3>(ctx, p);
   }
-  if (p.coutp % 128 == 0) {
-    if (bm == 32) return launch_dwpw_cfg<4, 1, 1, 1, PREC_F32>(ctx, p);
-    if (bm == 64) return launch_dwpw_cfg<2, 2, 2, 1, PREC_F32>(ctx, p);
-    return launch_dwpw_cfg<2, 2, 2, 2, PREC_F32>(ctx, p);
-  }
+  if (p.coutp % 128 == 0) return launch_dwpw_cfg<2, 2, 2, 2, PREC_F32>(ctx, p);
   if (p.coutp % 64 == 0) return launch_dwpw_cfg<1, 4, 2, 1, PREC_F32>(ctx, p);
   return launch_dwpw_cfg<1, 4, 1, 1, PREC_F32>(ctx, p);
 }
