@@ -2545,7 +2545,7 @@ int ta_launch_dwpw(ta_ctx* ctx, const ta_conv_launch& p_in, double flops) {
 #endif
   if (p.prec == PREC_F16X3) {
     // the lean kernel wherever the block has the shape it is written for (every f16x3 block of the detector's base); TA_DWPW_GENERIC: A/B
-    static const bool generic_only = getenv("TA_DWPW_GENERIC") != nullptr;
+    const bool generic_only = getenv("TA_DWPW_GENERIC") != nullptr;      // read per launch: the parity test flips it inside one process
     const bool lean_ok = !generic_only && p.dw_c % 32 == 0 && p.dw_c == p.n_slabs * 32 && p.dw_c <= 1024 && p.cout % 8 == 0 && p.act == TA_ACT_RELU &&
                          (p.out_fmt == TA_FMT_F32 || p.out_fmt == TA_FMT_SPLIT16);
     if (lean_ok) {

@@ -327,3 +327,59 @@ def test_window_kernel_equals_streaming_kernel(ctx, layer, tile, precision):
     assert np.abs(ref).max() > 0
     assert np.array_equal(outs['win_' + tile][0], ref), (layer, tile, float(np.abs(outs['win_' + tile][0] - ref).max()))
     assert np.array_equal(outs['auto'][0], ref)
+
+
+# ---- the detector's [depthwise 3x3 -> 1x1] block: rf_dwpw_kernel (written for this block) against conv_dwpw (generic tiles) ----------
+def _dwpw_block_program(C, cout, stride, split_out):
+    """frames -> conv 3x3 (4 -> C, exact f32) -> [dw3x3 (stride) -> 1x1 C -> cout] (f16x3) [-> 1x1 conv (f16x3): the block's output is then
+    stored pre-split] -> float32 out."""
+    rng = np.random.default_rng(1000 * C + 10 * cout + stride)
+    P = pack.Program(pack.MODEL_OPENPOSE, 'f16x3')
+    t0 = P.tensor(4, 1)
+    P.input_tensor = t0
+    P.input_stats = (np.array([-0.05] * 3 + [0.0]), np.array([0.08] * 3 + [0.0]))
+    t1 = P.tensor(C, 1)
+    P.conv(t0, t1, rng.normal(0, 0.3, (C, 3, 3, 3)).astype(np.float32), rng.normal(0, 0.1, C).astype(np.float32), act=pack.ACT_RELU, precision='f32')
+    t2 = P.tensor(cout, 0, name='block', f32=not split_out)
+    P.dwpw(t1, t2, rng.normal(0, 0.3, (C, 1, 3, 3)).astype(np.float32), rng.normal(0, 0.1, C).astype(np.float32),
+           rng.normal(0, 2.0 / np.sqrt(C), (cout, C, 1, 1)).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32),
+           stride=stride, precision='f16x3')
+    if split_out:
+        t3 = P.tensor(32, 0, name='out', f32=True)
+        P.conv(t2, t3, rng.normal(0, 0.05, (32, cout, 1, 1)).astype(np.float32), np.zeros(32, np.float32), precision='f16x3')
+        P.outputs = [t3]
+    else:
+        P.outputs = [t2]
+    return P
+
+
+@pytest.mark.parametrize('C,cout,stride,split_out', [(64, 64, 1, False), (64, 128, 2, False), (128, 128, 1, False), (128, 256, 2, False),
+                                                     (256, 256, 1, True), (32, 32, 1, False), (32, 64, 2, False), (96, 40, 1, False),
+                                                     (128, 128, 1, True), (64, 24, 1, False)])
+def test_rf_dwpw_kernel_equals_the_generic_kernel(ctx, monkeypatch, C, cout, stride, split_out):
+    """Same products in the same order: every output bit of the block must be the same whichever kernel ran it -- on maps that
+    do not fill their tiles (13 x 24, 5 x 3), across image boundaries (tiles of 64 / 128 raster-consecutive pixels), with cout
+    tiles of 32 / 64 / 128 and partial ones (40, 24), stride 1 and 2, float32 and pre-split outputs."""
+    from terran_amd import lib
+    prog = _dwpw_block_program(C, cout, stride, split_out)
+    tap = 'out' if split_out else 'block'
+    for n, h, w in ((3, 13, 24), (2, 5, 3), (1, 40, 40), (5, 20, 20)):
+        frames = ctx.upload(synth.frames(7 + n, n, h, w))
+        outs, kernels = {}, {}
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv('TA_DWPW_GENERIC', '1')
+            else:
+                monkeypatch.delenv('TA_DWPW_GENERIC', raising=False)
+            m = lib.Model(ctx, prog)
+            ctx.kernel_work(reset=True)
+            m.forward_frames(frames)
+            outs[generic] = m.read(tap).copy()
+            kernels[generic] = sorted(k for k in ctx.kernel_work() if 'dwpw' in k)
+            assert ctx.lib.ta_debug_range_check(ctx.h) == lib.OK
+            m.free()
+        frames.free()
+        assert all(k.startswith('rf_dwpw_kernel') for k in kernels[False]) and kernels[False], kernels
+        assert all(k.startswith('conv_dwpw') for k in kernels[True]) and kernels[True], kernels
+        assert np.isfinite(outs[False]).all() and np.abs(outs[False]).max() > 0
+        assert np.array_equal(outs[False], outs[True]), (C, cout, stride, split_out, n, h, w, float(np.abs(outs[False] - outs[True]).max()))
