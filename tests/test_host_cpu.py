@@ -773,3 +773,22 @@ def test_bench_line_is_compact():
     detail['per_model'] = {'error': 'RuntimeError: ' + prose}
     detail['cpu_baseline'] = {'error': 'OSError: ' + prose}
     assert len(bench.compact_line(detail)) < 8192
+
+
+def test_smi_counter_deltas():
+    """telemetry.SmiCounters.delta: joules, mean power and per-throttler residency (% of the region) from two readings of the SMI
+    accumulators; missing fields stay absent, a wrapped energy counter yields no energy figure."""
+    from terran_amd import telemetry
+    a = {'t': 10.0, 'energy_uj': 5.0e9, 'accumulation_counter': 1000, 'ppt_residency_acc': 100, 'socket_thm_residency_acc': 7, 'hbm_thm_residency_acc': 0}
+    b = {'t': 12.5, 'energy_uj': 8.25e9, 'accumulation_counter': 3000, 'ppt_residency_acc': 1700, 'socket_thm_residency_acc': 7, 'hbm_thm_residency_acc': 0,
+         'throttle_status': 4}
+    d = telemetry.SmiCounters.delta(a, b)
+    assert d['seconds'] == 2.5 and d['energy_j'] == 3250.0 and d['power_w_from_energy'] == 1300.0
+    assert d['throttle_residency_pct'] == {'ppt': 80.0, 'socket_thm': 0.0, 'hbm_thm': 0.0} and d['throttle_status'] == 4
+    assert telemetry.SmiCounters.delta(None, b) is None and telemetry.SmiCounters.delta(a, None) is None
+    wrapped = telemetry.SmiCounters.delta(dict(a, energy_uj=9e9), b)
+    assert 'energy_j' not in wrapped and wrapped['throttle_residency_pct']['ppt'] == 80.0
+    assert telemetry.SmiCounters.delta({'t': 0.0}, {'t': 1.0}) is None                 # nothing but time stamps: no reading
+    assert telemetry.SmiCounters(None).read() is None                                  # no PCI address: the probe is a no-op
+    s = telemetry.PowerSampler(None, bdf=None).start()
+    assert s.stop() == [] and s.summary() is None
