@@ -149,7 +149,10 @@ int ta_ctx_create(int device_id, ta_ctx** out) {
   // TERRAN_AMD_SPIN_WAIT=1 keeps the spinning wait (latency probes).
   {
     const char* spin = getenv("TERRAN_AMD_SPIN_WAIT");
-    if (!(spin && spin[0] && spin[0] != '0')) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    if (!(spin && spin[0] && spin[0] != '0')) {
+      (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+      (void)hipGetLastError();          // a runtime that refuses the flag on an already active device must not leave an error for the first launch check
+    }
   }
   ta_ctx* ctx = new ta_ctx();
   ctx->device = device_id;
