@@ -363,6 +363,8 @@ def compact_line(result, detail_path=None):
                 rf = row['roofline']
                 rows[name] = {'images_per_s': row.get('images_per_s'), 'bound': rf.get('bound'), 'achieved': rf.get('achieved'),
                               'unit': rf.get('unit'), 'frac': rf.get('frac')}
+                if isinstance(row.get('images_per_s_packed'), (int, float)):      # C2: the same call returning the packed result arrays of the C ABI
+                    rows[name]['images_per_s_packed'] = row['images_per_s_packed']   # (`images_per_s` builds the reference's list of dicts per detection)
         line['per_model'] = rows or {k: str(v)[:120] for k, v in pm.items()}
     if r.get('c2_retinaface_640'):
         line['c2_retinaface_640_images_per_s'] = r['c2_retinaface_640'].get('images_per_s')

@@ -728,7 +728,7 @@ def test_bench_line_is_compact():
     power = {'samples': 40, 'power_w_mean': 1301.2, 'sclk_mhz_mean': 1859.0, 'cap_w': 1400.0, 'what': prose}
     per_model = {}
     for prec in ('f16x3', 'f32'):
-        per_model['C2 RetinaFace 32x640x640 ' + prec] = {'images_per_s': 27000.1, 'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0,
+        per_model['C2 RetinaFace 32x640x640 ' + prec] = {'images_per_s': 17000.1, 'images_per_s_packed': 27000.5, 'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0,
                                                          'achieved': 1551.0, 'frac': 0.194, 'note': prose}}
         per_model['C3 ArcFace 256x3x112x112 ' + prec] = {'images_per_s': 16000.0, 'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0,
                                                          'achieved': 394.0, 'frac': 0.158}}
@@ -767,7 +767,7 @@ def test_bench_line_is_compact():
     assert set(d['roofline']) == {'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step',
                                   'algorithmic_gflop_per_launch', 'mfma_issue_frac', 'share_of_conv_time'}
     assert set(d['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and len(d['cpu_baseline']['sample']) <= 160
-    assert len(d['per_model']) == 6 and all(set(v) == {'images_per_s', 'bound', 'achieved', 'unit', 'frac'} for v in d['per_model'].values())
+    assert len(d['per_model']) == 6 and all(set(v) - {'images_per_s_packed'} == {'images_per_s', 'bound', 'achieved', 'unit', 'frac'} for v in d['per_model'].values())
     assert prose[:300] not in line
     # a failed secondary leg (its error string) must not break the line either
     detail['per_model'] = {'error': 'RuntimeError: ' + prose}
