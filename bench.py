@@ -794,47 +794,31 @@ def run(args):
         # Without a gloo group beside RCCL the gather stays ONE message at region end (a collective on the default group from
         # a side thread would race the barrier).
         streamed = use_dist and (gather_group is not None or backend != 'nccl')
-        gq = queue.Queue()
-
-        def flush(chunk):
-            allr = shard.gather_results(chunk, distlike)
-            n_messages[0] += 1
-            if allr is not None:
-                n_on_rank0[0] += len(allr)
-
-        def gather_worker():
-            buf = []
-            while True:
-                item = gq.get()
-                if item is None:
-                    break
-                buf.append(item)
-                if len(buf) == G:
-                    flush(buf)
-                    buf = []
-            if buf:
-                flush(buf)
+        sg = [None]
 
         def on_step(dets, feats, poses):                 # called per finished step, in step order
             if streamed:
-                gq.put(pack_step(dets, feats, poses))
+                sg[0].put(pack_step(dets, feats, poses))
             else:
                 with lock:
                     gathered.append(pack_step(dets, feats, poses) if use_dist else (dets, feats, poses))
 
         def gather_all():
             if streamed:
-                gq.put(None)
-                gt.result(timeout=600)
+                sg[0].finish()
+                n_on_rank0[0], n_messages[0] = sg[0].steps, sg[0].messages
             elif use_dist:
-                flush(list(gathered))
+                allr = shard.gather_results(list(gathered), distlike)
+                n_messages[0] = 1
+                n_on_rank0[0] = len(allr) if allr is not None else 0
             else:
                 n_on_rank0[0] = len(gathered)
         try:
             run_steps(2 * L, readers=readers)                                        # warm the readers' buffers (2 batches each)
             del gathered[:]
             sync()
-            gt = pool.submit(gather_worker) if streamed else None
+            if streamed:                                  # terran_amd.shard.StreamedGather: a gather thread of this rank
+                sg[0] = shard.StreamedGather(distlike, steps_per_message=G, keep=False)
             t0 = time.perf_counter()
             run_steps(k, readers=readers, on_step=on_step)
             tg = time.perf_counter()

@@ -185,6 +185,53 @@ def test_sharded_gather_gloo_world2(tmp_path):
     assert 'SHARD_OK' in outs[0]
 
 
+_STREAM_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from terran_amd import shard
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', rank=rank, world_size=int(os.environ['WORLD_SIZE']))
+K = 7                                          # steps per rank; 3 per message -> messages of 3, 3, 1 steps
+sg = shard.StreamedGather(dist, steps_per_message=3)
+for i in range(K):
+    time.sleep(0.01 * (1 + 3 * rank))          # the ranks run at different speeds: the collectives still pair up
+    sg.put((rank, i, np.full(2 + i, 10 * rank + i, np.int32)))
+res = sg.finish()
+if rank == 0:
+    assert sg.messages == 3 and sg.steps == 2 * K, (sg.messages, sg.steps)
+    flat = [(r, i, a.tolist()) for msg in res for (r, i, a) in msg]
+    want = []
+    for lo, hi in ((0, 3), (3, 6), (6, 7)):    # per message: rank 0's steps, then rank 1's, each in step order
+        for r in (0, 1):
+            want += [(r, i, [10 * r + i] * (2 + i)) for i in range(lo, hi)]
+    assert flat == want, flat
+    print('STREAM_OK')
+else:
+    assert res == [] and sg.steps == 0 and sg.messages == 3
+single = shard.StreamedGather(None, steps_per_message=2)          # no process group: everything stays local
+for i in range(3):
+    single.put(i)
+assert single.finish() == [[0, 1], [2]] and single.steps == 3
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_streamed_gather_gloo_world2(tmp_path):
+    """shard.StreamedGather (bench.py's ingest leg: per-step results travel to rank 0 while the run goes on): two gloo ranks of
+    different speed, 7 steps each in messages of 3 -- rank 0 ends up with every step of both ranks, rank-ordered inside a message."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_STREAM_WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'STREAM_OK' in outs[0]
+
+
 def test_raw_video_reader_framing():
     """Batch framing of the rawvideo rgb24 contract (terran/io/video/reader.py:88-117), no GPU: whole batches,
     a short final batch, trailing partial frame dropped, end of stream, prefetch thread shutdown."""
