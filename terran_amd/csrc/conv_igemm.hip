@@ -1605,6 +1605,10 @@ __global__ __launch_bounds__(64 * (CM * CN + NP), STAGES == 2 ? 4 : (CM * CN + N
   }
 
   // ================= consumer =================
+  // the MFMA waves ahead of the DMA-issuing producers in the CU's issue arbitration (TA_CONV_PRIO, A/B; s_setprio ignores EXEC)
+  if (p.cons_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.cons_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.cons_prio == 3) __builtin_amdgcn_s_setprio(3);
   const int cm = wave / CN, cn = wave % CN;
   int stage = 0;                                    // stage of the slab being consumed
   f32x16 acc[2][2];
@@ -1886,6 +1890,10 @@ __global__ __launch_bounds__(64 * (CM * CN + 4), (CM * CN + 4) / 4) void conv_ig
   }
 
   // ================= consumer =================
+  // the MFMA waves ahead of the DMA-issuing producers in the CU's issue arbitration (TA_CONV_PRIO, A/B; s_setprio ignores EXEC)
+  if (p.cons_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.cons_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.cons_prio == 3) __builtin_amdgcn_s_setprio(3);
   const int cm = wave / CN, cn = wave % CN;
   f32x16 acc[2][2];
 #pragma unroll
@@ -2090,6 +2098,10 @@ static int launch_split(ta_ctx* ctx, const ta_conv_launch& p) {
     if (p.res) ok = ok && p.res_fmt == SPLIT_FMT && fits(p.res_img, p.res_off0);
     if (p.out2) ok = ok && p.o2_fmt == SPLIT_FMT && fits(p.o2_img, p.o2_off0);
     q.fast_drain = ok ? 1 : 0;
+    {
+      static const int prio = getenv("TA_CONV_PRIO") ? atoi(getenv("TA_CONV_PRIO")) & 3 : 0;     // tools: A/B of the consumer waves' issue priority
+      q.cons_prio = prio;
+    }
     if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;     // slot 15: launches whose epilogue ran the specialised drain
   }
   static const bool late_b = getenv("TA_CONV_LATE_B") != nullptr;             // tools: A/B of the early slab-0 pixel-row DMAs
@@ -2151,6 +2163,10 @@ static int launch_win(ta_ctx* ctx, const ta_conv_launch& p) {
     if (p.res) ok = ok && p.res_fmt == TA_FMT_SPLIT16 && fits(p.res_img, p.res_off0);
     if (p.out2) ok = ok && p.o2_fmt == TA_FMT_SPLIT16 && fits(p.o2_img, p.o2_off0);
     q.fast_drain = ok ? 1 : 0;
+    {
+      static const int prio = getenv("TA_CONV_PRIO") ? atoi(getenv("TA_CONV_PRIO")) & 3 : 0;     // tools: A/B of the consumer waves' issue priority
+      q.cons_prio = prio;
+    }
     if (ok) ctx->conv_counts[TA_CV_COUNT - 1] += 1;
   }
   q.fast_div = (grid < (1 << 24) && (long long)p.M + BM < (1 << 24)) ? 1 : 0;

@@ -297,6 +297,7 @@ struct ta_conv_launch {
   // set-up needs no integer division (each one is a ~300-cycle dependent instruction chain in front of the first DMA)
   float r_nct, r_tile_blocks, r_Wo, r_Ho, r_HoWo;
   int fast_div;                                // 1: every dividend of the set-up is < 2^24 (exact in float32)
+  int cons_prio;                               // split-role kernels: s_setprio level of the consumer (MFMA) waves, 0..3 (0 = leave alone)
   int fast_drain;                              // 1: the lean epilogue applies (split-format tensors below 4 GB, cout % 8 == 0, no pool / K-split)
   int probe;                                   // tools only: bits 0..1: 1 = producers skip the pixel-row DMA after the ring is full,
                                                //             2 = no DMA at all after the ring is full (WRONG results);
